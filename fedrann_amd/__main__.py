@@ -1,0 +1,242 @@
+"""`python -m fedrann_amd` -- the fedrann command line for the GPU hot path.
+
+Keeps the reference's flags and defaults (fedrann/__main__.py:69-171) and its stage sequence
+(run_fedrann_pipeline :302-391) for stages 2-4: projection matrix -> embeddings -> k-NN ->
+overlaps.tsv.  Stage 1 (k-mer counting / sampling / kmer_searcher, count_kmers.py) is outside this
+build's scope; its products are accepted as inputs instead:
+
+    --kmer-searcher-output out/temp/kmer_searcher/output.bin --kmer-library out/temp/fwd_kmer_library.fasta
+        (what the reference leaves behind with --keep-intermediates), or
+    --feature-matrix feature_matrix.npz --kmer-counts counts.npy [--read-names names.txt]
+        (scipy.sparse.save_npz binary CSR of the rows to search; see feature_extraction.py).
+
+`-i/--input` with a FASTA/FASTQ file is accepted only to explain that.
+"""
+import argparse
+import logging
+import os
+from os.path import abspath, join
+from shutil import rmtree
+from typing import List
+
+import numpy as np
+import pandas as pd
+
+from . import __description__, __version__
+from . import global_variables
+from .feature_extraction import (build_feature_csr, embed_csr, get_feature_matrix, get_metadata,
+                                 load_feature_matrix_npz, save_feature_matrix_npz)
+from .nearest_neighbors import NNDescent_ava
+from .precompute import build_precompute_matrix, get_precompute_matrix
+
+LOG_FORMAT = "%(asctime)s - %(levelname)s - %(message)s"  # custom_logging.py:8
+logger = logging.getLogger("fedrann_amd")
+logger.setLevel(logging.DEBUG)
+
+
+def _setup_logging(logfile=None):
+    if not logger.handlers:
+        h = logging.StreamHandler()
+        h.setFormatter(logging.Formatter(LOG_FORMAT))
+        logger.addHandler(h)
+    if logfile:
+        fh = logging.FileHandler(logfile)
+        fh.setFormatter(logging.Formatter(LOG_FORMAT))
+        logger.addHandler(fh)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="fedrann", description=__description__,
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("-i", "--input", type=str, required=False, default=None,
+                   help="Path to the input FASTQ/FASTA file (needs the reference's stage-1 tools; "
+                        "use --kmer-searcher-output or --feature-matrix instead).")
+    p.add_argument("-o", "--output-dir", type=str, required=True, help="Directory to save output files.")
+    p.add_argument("-k", "--kmer-size", type=int, default=16, help="K-mer size for feature extraction.")
+    p.add_argument("--kmer-sample-fraction", type=float, default=0.005,
+                   help="Percentage of k-mer used to build feature matrix.")
+    p.add_argument("--kmer-min-multiplicity", type=int, default=2,
+                   help="Minimum allowed frequency of a k-mer in all reads.")
+    p.add_argument("--threads", type=int, default=1)
+    p.add_argument("--chunk-size", type=int, default=1000)
+    p.add_argument("-n", "--embedding-dimension", type=int, default=500)
+    p.add_argument("--nndescent-n-trees", type=int, default=300, help="Number of trees to use in NNDescent.")
+    p.add_argument("--nndescent-n-neighbors", type=int, default=50,
+                   help="Number of neighbors to use in building NNDescent index.")
+    p.add_argument("--seed", type=int, default=356115, help="Random seed for reproducibility.")
+    p.add_argument("--save-feature-matrix", action="store_true", default=False,
+                   help="Save the feature matrix to a file.")
+    p.add_argument("--keep-intermediates", action="store_true", default=False,
+                   help="Do not remove intermediate files")
+    p.add_argument("--mprof", action="store_true", default=False, help="Record memory usage.")
+    g = p.add_argument_group("hot-path entry points (GPU build)")
+    g.add_argument("--kmer-searcher-output", type=str, default=None,
+                   help="kmer_searcher output.bin (reference intermediate temp/kmer_searcher/output.bin).")
+    g.add_argument("--kmer-library", type=str, default=None,
+                   help="fwd_kmer_library.fasta (jellyfish dump with counts) for the IDF weights.")
+    g.add_argument("--feature-matrix", type=str, default=None,
+                   help="feature_matrix.npz: binary read x feature CSR (scipy.sparse.save_npz).")
+    g.add_argument("--kmer-counts", type=str, default=None,
+                   help="With --feature-matrix: .npy of forward-library counts (int, length F/2) or a "
+                        "fwd_kmer_library.fasta.")
+    g.add_argument("--read-names", type=str, default=None,
+                   help="With --feature-matrix: text file, one 'name<TAB>strand' (or just name) per row.")
+    g.add_argument("--device", type=int, default=None, help="GPU ordinal (default $LOCAL_RANK or 0).")
+    return p
+
+
+def parse_command_line_arguments(argv=None):
+    return build_parser().parse_args(argv)
+
+
+def get_neighbors_ava(embedding_matrix, nndescent_n_trees, nndescent_n_neighbors, leaf_size=200):
+    """Same call shape as the reference (__main__.py:174-199)."""
+    logger.info("Using exact GPU k-NN in place of NNDescent (n_trees = %s, leaf_size = %s are inert)",
+                nndescent_n_trees, leaf_size)
+    return NNDescent_ava().get_neighbors(
+        embedding_matrix, metric="cosine", index_n_neighbors=nndescent_n_neighbors,
+        n_trees=nndescent_n_trees, leaf_size=leaf_size, n_iters=None, diversify_prob=1.0,
+        pruning_degree_multiplier=1.5, low_memory=True, n_jobs=global_variables.threads,
+        seed=global_variables.seed, verbose=True)
+
+
+def get_output_dataframe(neighbor_matrix, neighbor_distances, read_names: List[str],
+                         strands: List[int]) -> pd.DataFrame:
+    """Vectorised equivalent of the reference's N x k Python loop (__main__.py:261-300).
+
+    Same rows in the same order with the same dtypes: a neighbour is skipped only when it is the
+    query row itself; neighbor_rank keeps the column number; the distance column is float32 (pandas
+    prints its shortest repr); a negative index aliases from the end like Python indexing does.
+    """
+    idx = np.asarray(neighbor_matrix)
+    dist = np.asarray(neighbor_distances)
+    n = idx.shape[0]
+    names = np.asarray(read_names, dtype=object)
+    orient = np.where(np.asarray(strands, dtype=np.int64) == 0, "+", "-").astype(object)
+    keep = idx != np.arange(n, dtype=idx.dtype)[:, None]
+    q, r = np.nonzero(keep)  # row-major = the loop's order
+    t = idx[q, r]
+    columns = {
+        "query_name": names[q],
+        "query_orientation": orient[q],
+        "target_name": names[t],
+        "target_orientation": orient[t],
+        "neighbor_rank": r.astype(np.int64),
+        "distance": dist[q, r],
+    }
+    df = pd.DataFrame(columns)
+    logger.debug("Output DataFrame shape: %s", df.shape)
+    return df
+
+
+def write_overlaps(path, neighbor_matrix, distances, read_names, strands):
+    df = get_output_dataframe(neighbor_matrix, distances, read_names, strands)
+    df.to_csv(path, sep="\t", index=False)  # __main__.py:385
+    return df.shape[0]
+
+
+def _load_counts(path):
+    if path.endswith(".npy"):
+        return np.load(path).astype(np.int64)
+    from .precompute import read_kmer_counts
+    return read_kmer_counts(path)
+
+
+def _load_names(path, nrows):
+    if path is None:
+        return ["row_%d" % i for i in range(nrows)], [0] * nrows
+    names, strands = [], []
+    with open(path) as f:
+        for line in f:
+            parts = line.rstrip("\n").split("\t")
+            names.append(parts[0])
+            strands.append(int(parts[1]) if len(parts) > 1 and parts[1] != "" else 0)
+    if len(names) != nrows:
+        raise ValueError("%s has %d lines, the feature matrix has %d rows" % (path, len(names), nrows))
+    return names, strands
+
+
+def run_fedrann_pipeline(*, output_dir, embedding_dimension, nndescent_n_trees,
+                         nndescent_n_neighbors, save_feature_matrix, keep_intermediates, chunk_size,
+                         kmer_searcher_output=None, kmer_library=None, feature_matrix=None,
+                         kmer_counts=None, read_names_path=None):
+    """Stages 2-4 of the reference pipeline (__main__.py:329-391)."""
+    if kmer_searcher_output:
+        logger.info("--- 1. (skipped) using kmer_searcher output %s ---", kmer_searcher_output)
+        # n_features = 2 * |forward library| (count_kmers.py:148)
+        from .precompute import read_kmer_counts
+        n_features = 2 * int(read_kmer_counts(kmer_library).size)
+        logger.info("--- 2. Generate dimension reduction and IDF matrix ---")
+        P, n_features = get_precompute_matrix(n_components=embedding_dimension,
+                                              counter_file=kmer_library, n_features=n_features)
+        logger.info("--- 3. Generate feature matrix ---")
+        indptr, indices, read_names, strands = build_feature_csr(kmer_searcher_output, n_features)
+        if save_feature_matrix:
+            save_feature_matrix_npz(join(output_dir, "feature_matrix.npz"), indptr, indices, n_features)
+        embedding_matrix = embed_csr(indptr, indices, P)
+    else:
+        logger.info("--- 1. (skipped) using feature matrix %s ---", feature_matrix)
+        indptr, indices, n_features = load_feature_matrix_npz(feature_matrix)
+        counts = _load_counts(kmer_counts)
+        logger.info("--- 2. Generate dimension reduction and IDF matrix ---")
+        P = build_precompute_matrix(counts, embedding_dimension, n_features=n_features)
+        logger.info("--- 3. Generate feature matrix ---")
+        read_names, strands = _load_names(read_names_path, indptr.size - 1)
+        if save_feature_matrix:
+            save_feature_matrix_npz(join(output_dir, "feature_matrix.npz"), indptr, indices, n_features)
+        embedding_matrix = embed_csr(indptr, indices, P)
+
+    logger.info("--- 4. Nearest Neighbors Search ---")
+    neighbor_matrix, distances = get_neighbors_ava(embedding_matrix,
+                                                   nndescent_n_trees=nndescent_n_trees,
+                                                   nndescent_n_neighbors=nndescent_n_neighbors)
+    del embedding_matrix
+    nbr_output_file = join(output_dir, "overlaps.tsv")
+    logger.debug("Saving overlap table to %s", nbr_output_file)
+    rows = write_overlaps(nbr_output_file, neighbor_matrix, distances, read_names, strands)
+    logger.debug("wrote %d overlap rows", rows)
+    if not keep_intermediates and global_variables.temp_dir and os.path.isdir(global_variables.temp_dir):
+        logger.debug("Removing intermediate files")
+        rmtree(global_variables.temp_dir)
+    logger.info("Pipeline completed.")
+
+
+def main(argv=None):
+    args = parse_command_line_arguments(argv)
+    global_variables.threads = args.threads
+    global_variables.seed = args.seed
+    if args.device is not None:
+        os.environ["FEDRANN_DEVICE"] = str(args.device)
+    output_dir = abspath(args.output_dir)
+    os.makedirs(output_dir, exist_ok=True)
+    global_variables.output_dir = output_dir
+    _setup_logging(join(output_dir, "fedrann.log"))
+    temp_dir = join(output_dir, "temp")
+    os.makedirs(temp_dir, exist_ok=True)
+    global_variables.temp_dir = temp_dir
+    logger.info("FEDRANN (MI355X hot path) version: %s", __version__)
+    logger.debug("Parameters: %s", args)
+    have_ks = bool(args.kmer_searcher_output)
+    have_fm = bool(args.feature_matrix)
+    if have_ks == have_fm:
+        raise SystemExit(
+            "give exactly one of --kmer-searcher-output (+ --kmer-library) or --feature-matrix "
+            "(+ --kmer-counts).  K-mer counting, sampling and kmer_searcher (stage 1 of the "
+            "reference, -i/--input) are not part of this build: run the reference with "
+            "--keep-intermediates and pass its temp/kmer_searcher/output.bin and "
+            "temp/fwd_kmer_library.fasta here.")
+    if have_ks and not args.kmer_library:
+        raise SystemExit("--kmer-searcher-output needs --kmer-library")
+    if have_fm and not args.kmer_counts:
+        raise SystemExit("--feature-matrix needs --kmer-counts")
+    run_fedrann_pipeline(
+        output_dir=output_dir, embedding_dimension=args.embedding_dimension,
+        nndescent_n_trees=args.nndescent_n_trees, nndescent_n_neighbors=args.nndescent_n_neighbors,
+        save_feature_matrix=args.save_feature_matrix, keep_intermediates=args.keep_intermediates,
+        chunk_size=args.chunk_size, kmer_searcher_output=args.kmer_searcher_output,
+        kmer_library=args.kmer_library, feature_matrix=args.feature_matrix,
+        kmer_counts=args.kmer_counts, read_names_path=args.read_names)
+
+
+if __name__ == "__main__":
+    main()

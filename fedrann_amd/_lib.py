@@ -1,0 +1,203 @@
+"""ctypes binding of include/fedrann_hip.h (libfedrann_hip.so).
+
+No fallback: if the library is missing or no GPU is visible, FedrannHipError is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfedrann_hip.so")
+
+# symbols declared in include/fedrann_hip.h (tests check that the library exports every one)
+SYMBOLS = (
+    "fdr_create", "fdr_destroy", "fdr_last_error", "fdr_device_info", "fdr_padded_dim",
+    "fdr_projection_load", "fdr_embed", "fdr_knn", "fdr_embed_knn", "fdr_embed_dev",
+    "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_last_kernel_ms",
+)
+FDR_MAX_K = 64
+FDR_MAX_DIM = 256
+
+
+class FedrannHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libfedrann_hip.so and declare the prototypes.  Needs no GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FedrannHipError(
+            "%s is missing: build it with `python -m fedrann_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+    L.fdr_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.fdr_destroy.argtypes = [vp]
+    L.fdr_last_error.argtypes = []
+    L.fdr_last_error.restype = ctypes.c_char_p
+    L.fdr_device_info.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
+    L.fdr_padded_dim.argtypes = [ctypes.c_int]
+    L.fdr_projection_load.argtypes = [vp, i64, i32, vp, vp, vp]
+    L.fdr_embed.argtypes = [vp, i64, vp, vp, vp]
+    L.fdr_knn.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+    L.fdr_embed_knn.argtypes = [vp, i64, vp, vp, i32, vp, vp, vp]
+    L.fdr_embed_dev.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.fdr_normalize_dev.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.fdr_knn_workspace_bytes.argtypes = [vp, i64, i64, i32, i32]
+    L.fdr_knn_workspace_bytes.restype = sz
+    L.fdr_knn_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, vp, sz, vp]
+    L.fdr_last_kernel_ms.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("fdr_last_error", "fdr_knn_workspace_bytes"):
+            fn.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+def _as(a, dtype, name):
+    b = np.ascontiguousarray(a, dtype=dtype)
+    if b.dtype != np.dtype(dtype):
+        raise TypeError("%s must be %s" % (name, np.dtype(dtype)))
+    return b
+
+
+class Context:
+    """One GPU context (= fdr_ctx).  Methods raise FedrannHipError on any non-zero return code."""
+
+    def __init__(self, device=0):
+        self._L = load_library()
+        h = ctypes.c_void_p()
+        rc = self._L.fdr_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise FedrannHipError("fdr_create(%d) failed (%d): %s" % (device, rc, self._err()))
+        self._h = h
+        self.device = int(device)
+        self.n_features = 0
+        self.d = 0
+
+    def _err(self):
+        return self._L.fdr_last_error().decode("utf-8", "replace")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise FedrannHipError("%s failed (%d): %s" % (what, rc, self._err()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fdr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- info ---------------------------------------------------------------------------------
+    def device_info(self):
+        buf = ctypes.create_string_buffer(256)
+        self._check(self._L.fdr_device_info(self._h, buf, 256), "fdr_device_info")
+        name, arch, cus, mem = buf.value.decode().split("|")
+        return {"name": name, "arch": arch, "cus": int(cus), "hbm_bytes": int(mem)}
+
+    def padded_dim(self, d):
+        dp = self._L.fdr_padded_dim(int(d))
+        if dp < 0:
+            raise FedrannHipError("embedding dimension %d unsupported (1..%d)" % (d, FDR_MAX_DIM))
+        return dp
+
+    def last_kernel_ms(self, which):
+        ms = ctypes.c_float()
+        self._check(self._L.fdr_last_kernel_ms(self._h, int(which), ctypes.byref(ms)),
+                    "fdr_last_kernel_ms")
+        return float(ms.value)
+
+    # -- host-pointer API -----------------------------------------------------------------------
+    def projection_load(self, p_indptr, p_cols, p_vals, n_features, d):
+        p_indptr = _as(p_indptr, np.int64, "p_indptr")
+        p_cols = _as(p_cols, np.int32, "p_cols")
+        p_vals = _as(p_vals, np.float32, "p_vals")
+        if p_indptr.shape != (int(n_features) + 1,):
+            raise ValueError("p_indptr must have n_features + 1 entries")
+        self._check(self._L.fdr_projection_load(self._h, int(n_features), int(d), _ptr(p_indptr),
+                                                _ptr(p_cols), _ptr(p_vals)), "fdr_projection_load")
+        self.n_features, self.d = int(n_features), int(d)
+
+    def embed(self, a_indptr, a_indices):
+        a_indptr = _as(a_indptr, np.int64, "a_indptr")
+        a_indices = _as(a_indices, np.int32, "a_indices")
+        n = a_indptr.shape[0] - 1
+        E = np.empty((n, self.d), dtype=np.float32)
+        self._check(self._L.fdr_embed(self._h, n, _ptr(a_indptr), _ptr(a_indices), _ptr(E)),
+                    "fdr_embed")
+        return E
+
+    def knn(self, E, k):
+        E = _as(E, np.float32, "E")
+        if E.ndim != 2:
+            raise ValueError("E must be 2-D")
+        n, d = E.shape
+        idx = np.empty((n, k), dtype=np.int32)
+        dist = np.empty((n, k), dtype=np.float32)
+        self._check(self._L.fdr_knn(self._h, _ptr(E), n, d, int(k), _ptr(idx), _ptr(dist)),
+                    "fdr_knn")
+        return idx, dist
+
+    def embed_knn(self, a_indptr, a_indices, k, return_embedding=False):
+        a_indptr = _as(a_indptr, np.int64, "a_indptr")
+        a_indices = _as(a_indices, np.int32, "a_indices")
+        n = a_indptr.shape[0] - 1
+        idx = np.empty((n, k), dtype=np.int32)
+        dist = np.empty((n, k), dtype=np.float32)
+        E = np.empty((n, self.d), dtype=np.float32) if return_embedding else None
+        self._check(self._L.fdr_embed_knn(self._h, n, _ptr(a_indptr), _ptr(a_indices), int(k),
+                                          _ptr(idx), _ptr(dist), _ptr(E)), "fdr_embed_knn")
+        return (idx, dist, E) if return_embedding else (idx, dist)
+
+    # -- device-pointer API (integers are raw device addresses, e.g. torch.Tensor.data_ptr()) -----
+    def embed_dev(self, n_rows, d_indptr, d_indices, d_E, stream=0):
+        self._check(self._L.fdr_embed_dev(self._h, int(n_rows), d_indptr, d_indices, d_E,
+                                          stream or None), "fdr_embed_dev")
+
+    def normalize_dev(self, d_E, n_rows, d, d_Ehat, d_zero, stream=0):
+        self._check(self._L.fdr_normalize_dev(self._h, d_E, int(n_rows), int(d), d_Ehat, d_zero,
+                                              stream or None), "fdr_normalize_dev")
+
+    def knn_workspace_bytes(self, nq, nt, d, k):
+        return int(self._L.fdr_knn_workspace_bytes(self._h, int(nq), int(nt), int(d), int(k)))
+
+    def knn_dev(self, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
+                d_ws, ws_bytes, stream=0):
+        self._check(self._L.fdr_knn_dev(self._h, d_Qhat, d_qzero, int(nq), d_That, d_tzero,
+                                        int(nt), int(t_base), int(d), int(k), d_idx, d_dist, d_ws,
+                                        int(ws_bytes), stream or None), "fdr_knn_dev")
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on device $FEDRANN_DEVICE (default: LOCAL_RANK, else 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("FEDRANN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = Context(dev)
+    return _default_ctx

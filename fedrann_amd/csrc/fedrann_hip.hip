@@ -1,0 +1,823 @@
+// fedrann_hip.hip -- gfx950 (MI355X / CDNA4) kernels + C-ABI for FEDRANN's hot path.
+//
+//   K1 embed_csr_kernel      E = A . P          (feature_extraction.py:167-213 in the reference)
+//   K2 normalize_rows_kernel E -> Ehat          (done inside pynndescent in the reference)
+//   K3 knn_tile_kernel       exact cosine top-k (nearest_neighbors.py:39-55 -> pynndescent)
+//   K4 knn_merge_kernel      merge of per-segment top-k lists
+//
+// Written for wave64 / MFMA / 160 KB LDS directly; there is no other backend.
+// ABI: include/fedrann_hip.h.  Design notes and rooflines: DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/fedrann_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+#define FDR_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? FDR_E_NOMEM : FDR_E_HIP, "%s failed: %s",  \
+                        #expr, hipGetErrorString(e_));                                         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// K1  E = A . P   -- CSR-row-parallel, one wave per read row.
+//
+// P (F x d) is "very sparse": >= 90 % of its feature rows are empty (density 1/sqrt(F)), so the
+// projection is stored as
+//   ftab[w]   = { bits: which of features 32w..32w+31 have a non-empty P row,
+//                 prefix: number of non-empty rows among features < 32w }           (8 B / 32 features)
+//   crow[r]   = offset of the r-th non-empty row's entries,   ent[q] = { column, fp32 bits }.
+// A wave streams its row's column ids 64 at a time (coalesced), tests the bitmap (L2 resident),
+// and only the few hits touch crow/ent.  Hits are applied in ascending feature order by the
+// whole wave (lane l owns columns l, l+64, ...), which reproduces scipy's sequential fp32 sums.
+// ------------------------------------------------------------------------------------------
+template <int DP>
+__global__ __launch_bounds__(256) void embed_csr_kernel(
+    long long n_rows, const long long *__restrict__ a_indptr, const int *__restrict__ a_indices,
+    long long n_features, const uint2 *__restrict__ ftab, const int *__restrict__ crow,
+    const uint2 *__restrict__ ent, int d, float *__restrict__ E) {
+    constexpr int NACC = DP / 64;
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long row = wave0; row < n_rows; row += nwaves) {
+        float acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+        const long long beg = a_indptr[row], end = a_indptr[row + 1];
+        for (long long base = beg; base < end; base += 64) {
+            const long long pos = base + lane;
+            int f = -1;
+            if (pos < end) f = a_indices[pos];
+            bool hit = false;
+            int s = 0, e = 0;
+            uint2 first = make_uint2(0u, 0u);
+            if (f >= 0 && (long long)f < n_features) {
+                const uint2 w = ftab[f >> 5];
+                const unsigned bit = 1u << (f & 31);
+                if (w.x & bit) {
+                    hit = true;
+                    const int r = (int)w.y + __popc(w.x & (bit - 1u));
+                    s = crow[r];
+                    e = crow[r + 1];
+                    first = ent[s];
+                }
+            }
+            u64 m = __ballot(hit);
+            while (m) {  // wave-uniform: hits in ascending lane = ascending feature order
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const int ss = __builtin_amdgcn_readlane(s, src);
+                const int ee = __builtin_amdgcn_readlane(e, src);
+                unsigned c = (unsigned)__builtin_amdgcn_readlane((int)first.x, src);
+                float v = __int_as_float(__builtin_amdgcn_readlane((int)first.y, src));
+                int q = ss;
+                while (true) {
+#pragma unroll
+                    for (int i = 0; i < NACC; ++i)
+                        if (c == (unsigned)(lane + 64 * i)) acc[i] += v;
+                    if (++q >= ee) break;
+                    const uint2 en = ent[q];  // same address in every lane
+                    c = en.x;
+                    v = __uint_as_float(en.y);
+                }
+            }
+        }
+        float *out = E + row * (long long)d;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            if (lane + 64 * i < d) out[lane + 64 * i] = acc[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2  row normalisation into the k-NN kernel's layout.
+//
+// One lane per row runs the canonical chain n = fma(x_k, x_k, n), k ascending (the same order
+// the MFMA uses along K), rinv = (float)(1/sqrt((double)n)), xhat_k = x_k * rinv.  A 64-row tile is
+// staged through LDS so that both the global read and the global write are coalesced.
+// Output row: DP floats, zero padded; inside each group of 8 components the order is
+// [k0 k2 k4 k6 | k1 k3 k5 k7] so that lane-half h of the MFMA reads its four K-steps
+// (components 8g + 2s + h, s = 0..3) as ONE 16-byte access.
+// ------------------------------------------------------------------------------------------
+template <int DP, int RB>
+__global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restrict__ E,
+                                                            long long n_rows, int d,
+                                                            float *__restrict__ Ehat,
+                                                            unsigned char *__restrict__ zero) {
+    __shared__ float tile[RB][DP + 1];  // +1: the per-lane row walk below is bank-conflict free
+    const int tid = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * RB;
+    const int nr = (int)min((long long)RB, n_rows - row0);
+    const float *src = E + row0 * (long long)d;
+    for (int i = tid; i < RB * DP; i += 64) tile[i / DP][i % DP] = 0.0f;
+    __syncthreads();
+    const int total = nr * d;
+    for (int i = tid; i < total; i += 64) tile[i / d][i % d] = src[i];
+    __syncthreads();
+    if (tid < RB) {
+        float n = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < DP; ++k) {
+            const float x = tile[tid][k];
+            n = __builtin_fmaf(x, x, n);
+        }
+        float ri = 0.0f;
+        if (n > 0.0f) ri = (float)(1.0 / sqrt((double)n));
+#pragma unroll 8
+        for (int k = 0; k < DP; ++k) tile[tid][k] = tile[tid][k] * ri;
+        if (tid < nr) zero[row0 + tid] = n > 0.0f ? 0 : 1;
+    }
+    __syncthreads();
+    float *dst = Ehat + row0 * (long long)DP;
+    for (int i = tid; i < nr * DP; i += 64) {
+        const int r = i / DP, p = i % DP;
+        const int g = p >> 3, hh = (p >> 2) & 1, s = p & 3;
+        dst[i] = tile[r][8 * g + 2 * s + hh];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3  tiled exact cosine k-NN.
+//
+// Workgroup = 8 waves = 256 query rows; grid = (query blocks, target segments).  Each wave keeps
+// its 32 queries as the B operand of v_mfma_f32_32x32x2_f32 in DP/2 VGPRs for the whole kernel
+// and streams 32-target tiles (A operand) from a double-buffered, XOR-swizzled LDS image shared by
+// the 8 waves.  The MFMA accumulates along K exactly like an fp32 fmaf chain in ascending
+// component order, so every similarity is bit-identical to the CPU oracle's chain_dot().
+//
+// Top-k: one list of K (dist,idx) keys per query in LDS (key = dist bits << 32 | idx, unsigned
+// order == (dist asc, idx asc)); the list is an unsorted set whose maximum (tau, taupos) is kept
+// in registers.  Fast path per tile: max of the 16 accumulators -> one distance -> compare with
+// tau.  Slow path (rare after warm-up): candidates are visited in ascending target order --
+// lane-half 0 takes tile rows 0..15, then lane-half 1 rows 16..31 -- so a strict "dist < tau" is
+// exact under the (dist, idx) order; an accepted candidate replaces the maximum and the K keys
+// are rescanned for the new maximum.
+// ------------------------------------------------------------------------------------------
+#define KEY_INF 0x7F800000FFFFFFFFull
+
+__device__ __forceinline__ float dist_from_sim(float c) {
+    float dv = 1.0f - c;
+    dv = dv < 0.0f ? 0.0f : dv;
+    dv = dv > 1.0f ? 1.0f : dv;
+    return dv;
+}
+
+template <int DP>
+__global__ __launch_bounds__(512, (DP <= 128 ? 4 : 2)) void knn_tile_kernel(
+    const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
+    const float *__restrict__ Th, const unsigned char *__restrict__ tzero, int nt, int t_base,
+    int seg_len, int K, int nq_pad, u64 *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TILE_FLOATS = 32 * DP;
+    constexpr int SLOTS = DP / 4;  // 16-byte slots per row
+    float *tiles = reinterpret_cast<float *>(smem);                       // 2 * TILE_FLOATS
+    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * TILE_FLOATS * 4);     // K * 256
+    unsigned char *tzf = smem + 2 * TILE_FLOATS * 4 + (size_t)K * 256 * 8;  // 2 * 32
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int ql = wave * 32 + j;
+    const int qg = blockIdx.x * 256 + ql;
+    const int qrow = qg < nq ? qg : nq - 1;
+    const bool qz = qzero[qrow] != 0;
+
+    // queries: this lane's B fragments for all DP/2 K-steps
+    float b[DP / 2];
+    {
+        const f32x4 *qp = reinterpret_cast<const f32x4 *>(Qh + (size_t)qrow * DP);
+#pragma unroll
+        for (int g = 0; g < DP / 8; ++g) {
+            const f32x4 v = qp[2 * g + h];
+            b[4 * g + 0] = v.x;
+            b[4 * g + 1] = v.y;
+            b[4 * g + 2] = v.z;
+            b[4 * g + 3] = v.w;
+        }
+    }
+    for (int i = tid; i < K * 256; i += 512) lists[i] = KEY_INF;
+    float tau = __builtin_inff();
+    int taupos = 0;
+
+    const int t_begin = blockIdx.y * seg_len;
+    const int t_end = min(nt, t_begin + seg_len);
+    const int ntiles = (t_end - t_begin + 31) >> 5;
+
+    constexpr int LPT = TILE_FLOATS / 4 / 512;  // 16-byte loads per thread per tile
+    f32x4 stage[LPT];
+    unsigned char stage_flag = 0;
+
+    auto load_tile = [&](int t) {
+        const int trow0 = t_begin + t * 32;
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            const int f4 = tid + 512 * u;
+            const int row = f4 / SLOTS, slot = f4 % SLOTS;
+            const int trow = trow0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (trow < t_end) v = reinterpret_cast<const f32x4 *>(Th + (size_t)trow * DP)[slot];
+            stage[u] = v;
+        }
+        if (tid < 32) {
+            const int trow = trow0 + tid;
+            stage_flag = trow < t_end ? tzero[trow] : 0;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        f32x4 *tb = reinterpret_cast<f32x4 *>(tiles + buf * TILE_FLOATS);
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            const int f4 = tid + 512 * u;
+            const int row = f4 / SLOTS, slot = f4 % SLOTS;
+            tb[row * SLOTS + (slot ^ (row & 15))] = stage[u];
+        }
+        if (tid < 32) tzf[buf * 32 + tid] = stage_flag;
+    };
+
+    if (ntiles > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) load_tile(t + 1);
+
+        // ---- 32 targets x 32 queries x DP: DP/2 chained MFMAs ----
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        {
+            const f32x4 *tb = reinterpret_cast<const f32x4 *>(tiles + buf * TILE_FLOATS) + j * SLOTS;
+            const int sw = j & 15;
+#pragma unroll
+            for (int g = 0; g < DP / 8; ++g) {
+                const f32x4 a = tb[(2 * g + h) ^ sw];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * g + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * g + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * g + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * g + 3], acc, 0, 0, 0);
+            }
+        }
+        // acc[r] = <query j, target row (r&3) + 8*(r>>2) + 4*h of this tile>
+
+        if (__any(qz)) {  // an all-zero query is at distance 0 from all-zero targets, 1 from the rest
+            if (qz) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[r] = tzf[buf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] ? 1.0f : 0.0f;
+            }
+        }
+
+        // ---- fast path: can any of my 16 candidates beat the current k-th best? ----
+        float mx = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+        const bool hot = dist_from_sim(mx) < tau;
+
+        if (__any(hot)) {
+            // regroup so that lane-half h holds tile rows 16h .. 16h+15 in ascending order
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float lo = acc[r], hi = acc[r + 8];
+                const float recv = __shfl_xor(h == 0 ? hi : lo, 32);
+                // position p = 8u + 4w + x  <->  row 16h + p, with r = 4u + x
+                const int u = r >> 2, x = r & 3;
+                v[8 * u + x] = h == 0 ? lo : recv;      // rows 16h + 8u + x
+                v[8 * u + 4 + x] = h == 0 ? recv : hi;  // rows 16h + 8u + 4 + x
+            }
+            const int row0 = t_begin + t * 32 + 16 * h;  // target row of position 0
+            unsigned mask = 0;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const bool ok = (dist_from_sim(v[p]) < tau) && (row0 + p < t_end);
+                mask |= ok ? (1u << p) : 0u;
+            }
+#pragma unroll 1
+            for (int phase = 0; phase < 2; ++phase) {
+                unsigned m = (h == phase) ? mask : 0u;
+                while (__any(m != 0u)) {
+                    if (m != 0u) {
+                        const int p = __ffs(m) - 1;
+                        m &= m - 1u;
+                        float c = v[0];
+#pragma unroll
+                        for (int i = 1; i < 16; ++i) c = (p == i) ? v[i] : c;
+                        const float dist = dist_from_sim(c);
+                        if (dist < tau) {
+                            const u64 key = ((u64)__float_as_uint(dist) << 32) |
+                                            (unsigned)(t_base + row0 + p);
+                            lists[taupos * 256 + ql] = key;
+                            u64 best = 0;
+                            int bp = 0;
+#pragma unroll 4
+                            for (int e = 0; e < K; ++e) {
+                                const u64 kv = lists[e * 256 + ql];
+                                if (kv > best) {
+                                    best = kv;
+                                    bp = e;
+                                }
+                            }
+                            taupos = bp;
+                            tau = __uint_as_float((unsigned)(best >> 32));
+                        }
+                    }
+                }
+                // hand the list's maximum to the other lane of the query
+                const float tau_o = __shfl_xor(tau, 32);
+                const int pos_o = __shfl_xor(taupos, 32);
+                if (h != phase) {
+                    tau = tau_o;
+                    taupos = pos_o;
+                }
+            }
+        }
+
+        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- write this segment's lists: partial[seg][query][K] ----
+    __syncthreads();
+    {
+        u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * 256) * K;
+        const int total = 256 * K;
+        for (int i = tid; i < total; i += 512) {
+            const int q = i / K, e = i % K;
+            out[i] = lists[e * 256 + q];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4  merge: one wave per query selects the K smallest keys out of nseg * K, ascending.
+// Keys are unique (each target lives in exactly one segment), so "smallest key greater than the
+// previous pick" enumerates them in order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_merge_kernel(const u64 *__restrict__ partial, int nseg,
+                                                        int nq, int nq_pad, int K,
+                                                        int *__restrict__ idx_out,
+                                                        float *__restrict__ dist_out) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int M = nseg * K;
+    u64 prev1 = 0;  // previous pick + 1 (0 = none yet)
+    u64 mine = 0;
+    for (int r = 0; r < K; ++r) {
+        u64 best = ~0ull;
+        for (int m = lane; m < M; m += 64) {
+            const int seg = m / K, e = m - seg * K;
+            const u64 kv = partial[((size_t)seg * nq_pad + q) * K + e];
+            if (kv + 1 > prev1 && kv < best) best = kv;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const u64 o = __shfl_xor(best, off);
+            best = o < best ? o : best;
+        }
+        prev1 = best + 1;
+        if (lane == r) mine = best;
+    }
+    if (lane < K) {
+        idx_out[(size_t)q * K + lane] = (int)(unsigned)(mine & 0xffffffffull);
+        dist_out[(size_t)q * K + lane] = __uint_as_float((unsigned)(mine >> 32));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return FDR_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(FDR_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        }
+        cap = bytes;
+        return FDR_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct fdr_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    // projection
+    long long n_features = 0;
+    int d = 0;
+    long long p_nnz = 0, p_rows = 0;
+    DevBuf ftab, crow, ent;
+    // scratch for the host-pointer API
+    DevBuf a_indptr, a_indices, E, Ehat, zero, idx, dist, ws;
+    // timing
+    hipEvent_t ev[4][2];
+    bool ev_valid[4] = {false, false, false, false};
+};
+
+static int use_device(fdr_ctx *ctx) {
+    if (!ctx) return fail(FDR_E_ARG, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return FDR_OK;
+}
+
+FDR_EXPORT const char *fdr_last_error(void) { return g_err; }
+
+FDR_EXPORT int fdr_padded_dim(int d) {
+    if (d <= 0) return FDR_E_ARG;
+    if (d <= 128) return 128;
+    if (d <= 256) return 256;
+    return FDR_E_ARG;
+}
+
+FDR_EXPORT int fdr_create(int device_id, fdr_ctx **out) {
+    if (!out) return fail(FDR_E_ARG, "fdr_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (n <= 0) return fail(FDR_E_HIP, "no HIP device visible: the MI355X path cannot run");
+    if (device_id < 0 || device_id >= n)
+        return fail(FDR_E_ARG, "device %d out of range (have %d)", device_id, n);
+    fdr_ctx *c = new (std::nothrow) fdr_ctx();
+    if (!c) return fail(FDR_E_NOMEM, "out of host memory");
+    c->device = device_id;
+    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(hipGetDeviceProperties(&c->prop, device_id));
+    c->num_cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreate(&c->ev[i][k]));
+    *out = c;
+    return FDR_OK;
+}
+
+FDR_EXPORT int fdr_destroy(fdr_ctx *ctx) {
+    if (!ctx) return FDR_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->ftab, &ctx->crow, &ctx->ent, &ctx->a_indptr, &ctx->a_indices, &ctx->E,
+                      &ctx->Ehat, &ctx->zero, &ctx->idx, &ctx->dist, &ctx->ws};
+    for (DevBuf *b : bufs) b->release();
+    for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ctx->ev[i][k]);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return FDR_OK;
+}
+
+FDR_EXPORT int fdr_device_info(fdr_ctx *ctx, char *buf, int buflen) {
+    if (!ctx || !buf || buflen <= 0) return fail(FDR_E_ARG, "fdr_device_info: bad argument");
+    snprintf(buf, (size_t)buflen, "%s|%s|%d|%zu", ctx->prop.name, ctx->prop.gcnArchName,
+             ctx->prop.multiProcessorCount, (size_t)ctx->prop.totalGlobalMem);
+    return FDR_OK;
+}
+
+FDR_EXPORT int fdr_last_kernel_ms(fdr_ctx *ctx, int which, float *ms_out) {
+    if (!ctx || !ms_out || which < 0 || which > 3) return fail(FDR_E_ARG, "bad argument");
+    if (!ctx->ev_valid[which]) return fail(FDR_E_STATE, "kernel %d has not been launched", which);
+    HIP_TRY(hipEventSynchronize(ctx->ev[which][1]));
+    HIP_TRY(hipEventElapsedTime(ms_out, ctx->ev[which][0], ctx->ev[which][1]));
+    return FDR_OK;
+}
+
+// ---- projection ------------------------------------------------------------------------------
+FDR_EXPORT int fdr_projection_load(fdr_ctx *ctx, int64_t n_features, int32_t d,
+                                   const int64_t *p_indptr, const int32_t *p_cols,
+                                   const float *p_vals) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (n_features <= 0 || n_features > 0x7fffffffll || !p_indptr)
+        return fail(FDR_E_ARG, "projection: bad n_features %lld", (long long)n_features);
+    if (fdr_padded_dim(d) < 0)
+        return fail(FDR_E_ARG, "projection: embedding dimension %d unsupported (1..%d)", d,
+                    FDR_MAX_DIM);
+    const int64_t nnz = p_indptr[n_features];
+    if (p_indptr[0] != 0 || nnz < 0 || nnz > 0x7fffffffll || (nnz > 0 && (!p_cols || !p_vals)))
+        return fail(FDR_E_ARG, "projection: bad CSR arrays");
+    const int64_t nwords = (n_features + 31) / 32;
+    std::vector<uint2> ftab((size_t)nwords);
+    std::vector<int> crow;
+    std::vector<uint2> ent((size_t)std::max<int64_t>(nnz, 1));
+    crow.reserve(1024);
+    unsigned rows = 0;
+    for (int64_t w = 0; w < nwords; ++w) {
+        unsigned bits = 0;
+        const unsigned prefix = rows;
+        const int64_t f0 = w * 32, f1 = std::min<int64_t>(n_features, f0 + 32);
+        for (int64_t f = f0; f < f1; ++f) {
+            const int64_t s = p_indptr[f], e = p_indptr[f + 1];
+            if (e < s || e > nnz) return fail(FDR_E_ARG, "projection: indptr not monotone at %lld", (long long)f);
+            if (e > s) {
+                bits |= 1u << (unsigned)(f - f0);
+                crow.push_back((int)s);
+                ++rows;
+                for (int64_t q = s; q < e; ++q) {
+                    if (p_cols[q] < 0 || p_cols[q] >= d)
+                        return fail(FDR_E_ARG, "projection: column %d out of range at nnz %lld",
+                                    p_cols[q], (long long)q);
+                    uint32_t vb;
+                    memcpy(&vb, &p_vals[q], 4);
+                    ent[(size_t)q] = make_uint2((unsigned)p_cols[q], vb);
+                }
+            }
+        }
+        ftab[(size_t)w] = make_uint2(bits, prefix);
+    }
+    crow.push_back((int)nnz);
+    if ((rc = ctx->ftab.reserve(ftab.size() * sizeof(uint2)))) return rc;
+    if ((rc = ctx->crow.reserve(crow.size() * sizeof(int)))) return rc;
+    if ((rc = ctx->ent.reserve(ent.size() * sizeof(uint2)))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->ftab.p, ftab.data(), ftab.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->crow.p, crow.data(), crow.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->ent.p, ent.data(), ent.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->n_features = n_features;
+    ctx->d = d;
+    ctx->p_nnz = nnz;
+    ctx->p_rows = rows;
+    return FDR_OK;
+}
+
+// ---- launches --------------------------------------------------------------------------------
+static int launch_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *d_indptr,
+                        const int32_t *d_indices, float *d_E, hipStream_t st) {
+    if (ctx->n_features <= 0) return fail(FDR_E_STATE, "embed: no projection loaded");
+    if (n_rows < 0) return fail(FDR_E_ARG, "embed: n_rows < 0");
+    if (n_rows == 0) return FDR_OK;
+    const int dp = fdr_padded_dim(ctx->d);
+    const long long blocks_needed = (n_rows + 3) / 4;
+    const int grid = (int)std::min<long long>(blocks_needed, (long long)ctx->num_cus * 8 * 4);
+    HIP_TRY(hipEventRecord(ctx->ev[0][0], st));
+    if (dp == 128)
+        hipLaunchKernelGGL(embed_csr_kernel<128>, dim3(grid), dim3(256), 0, st, (long long)n_rows,
+                           (const long long *)d_indptr, d_indices, ctx->n_features,
+                           (const uint2 *)ctx->ftab.p, (const int *)ctx->crow.p,
+                           (const uint2 *)ctx->ent.p, ctx->d, d_E);
+    else
+        hipLaunchKernelGGL(embed_csr_kernel<256>, dim3(grid), dim3(256), 0, st, (long long)n_rows,
+                           (const long long *)d_indptr, d_indices, ctx->n_features,
+                           (const uint2 *)ctx->ftab.p, (const int *)ctx->crow.p,
+                           (const uint2 *)ctx->ent.p, ctx->d, d_E);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev[0][1], st));
+    ctx->ev_valid[0] = true;
+    return FDR_OK;
+}
+
+static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int d, float *d_Ehat,
+                            uint8_t *d_zero, hipStream_t st) {
+    const int dp = fdr_padded_dim(d);
+    if (dp < 0) return fail(FDR_E_ARG, "normalize: dimension %d unsupported (1..%d)", d, FDR_MAX_DIM);
+    if (n_rows < 0) return fail(FDR_E_ARG, "normalize: n_rows < 0");
+    if (n_rows == 0) return FDR_OK;
+    const int rb = dp == 128 ? 64 : 32;
+    const long long grid = (n_rows + rb - 1) / rb;
+    if (grid > 0x7fffffffll) return fail(FDR_E_ARG, "normalize: too many rows");
+    HIP_TRY(hipEventRecord(ctx->ev[1][0], st));
+    if (dp == 128)
+        hipLaunchKernelGGL((normalize_rows_kernel<128, 64>), dim3((unsigned)grid), dim3(64), 0, st,
+                           d_E, (long long)n_rows, d, d_Ehat, d_zero);
+    else
+        hipLaunchKernelGGL((normalize_rows_kernel<256, 32>), dim3((unsigned)grid), dim3(64), 0, st,
+                           d_E, (long long)n_rows, d, d_Ehat, d_zero);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev[1][1], st));
+    ctx->ev_valid[1] = true;
+    return FDR_OK;
+}
+
+struct KnnPlan {
+    int nqb, nseg, seg_len, nq_pad;
+    size_t partial_bytes;
+};
+
+static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int k) {
+    KnnPlan p;
+    p.nqb = (int)((nq + 255) / 256);
+    p.nq_pad = p.nqb * 256;
+    // enough workgroups to fill 2 per CU several times over, segments not shorter than 2048 targets
+    const long long want = (long long)ctx->num_cus * 8;
+    long long nseg = (want + p.nqb - 1) / std::max(p.nqb, 1);
+    const long long max_seg = std::max<long long>(1, nt / 2048);
+    nseg = std::max<long long>(1, std::min<long long>(std::min<long long>(nseg, max_seg), 64));
+    long long seg_len = (nt + nseg - 1) / nseg;
+    seg_len = (seg_len + 31) / 32 * 32;
+    nseg = (nt + seg_len - 1) / seg_len;
+    p.nseg = (int)nseg;
+    p.seg_len = (int)seg_len;
+    p.partial_bytes = (size_t)p.nseg * p.nq_pad * (size_t)k * sizeof(u64);
+    return p;
+}
+
+FDR_EXPORT size_t fdr_knn_workspace_bytes(fdr_ctx *ctx, int64_t nq, int64_t nt, int32_t d,
+                                          int32_t k) {
+    (void)d;
+    if (!ctx || nq <= 0 || nt <= 0 || k <= 0) return 0;
+    return knn_plan(ctx, nq, nt, k).partial_bytes;
+}
+
+static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
+                      const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base,
+                      int d, int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes,
+                      hipStream_t st) {
+    const int dp = fdr_padded_dim(d);
+    if (dp < 0) return fail(FDR_E_ARG, "knn: dimension %d unsupported (1..%d)", d, FDR_MAX_DIM);
+    if (k < 1 || k > FDR_MAX_K) return fail(FDR_E_ARG, "knn: k=%d unsupported (1..%d)", k, FDR_MAX_K);
+    if (nq < 0 || nt < k) return fail(FDR_E_ARG, "knn: need n_targets (%lld) >= k (%d)", (long long)nt, k);
+    if (nt + t_base > 0x7fffffffll || nq > 0x7fffffffll)
+        return fail(FDR_E_ARG, "knn: row numbers exceed int32");
+    if (nq == 0) return FDR_OK;
+    if (!d_Qhat || !d_qzero || !d_That || !d_tzero || !d_idx || !d_dist || !d_ws)
+        return fail(FDR_E_ARG, "knn: null device pointer");
+    const KnnPlan p = knn_plan(ctx, nq, nt, k);
+    if (ws_bytes < p.partial_bytes)
+        return fail(FDR_E_ARG, "knn: workspace %zu < required %zu bytes", ws_bytes, p.partial_bytes);
+    const size_t lds = (size_t)2 * 32 * dp * 4 + (size_t)k * 256 * 8 + 64;
+    if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn: k=%d, d=%d needs %zu B of LDS (> 160 KiB)", k, d, lds);
+    dim3 grid((unsigned)p.nqb, (unsigned)p.nseg);
+    HIP_TRY(hipEventRecord(ctx->ev[2][0], st));
+    if (dp == 128) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(knn_tile_kernel<128>, grid, dim3(512), lds, st, d_Qhat, d_qzero, (int)nq,
+                           d_That, d_tzero, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, (u64 *)d_ws);
+    } else {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<256>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(knn_tile_kernel<256>, grid, dim3(512), lds, st, d_Qhat, d_qzero, (int)nq,
+                           d_That, d_tzero, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, (u64 *)d_ws);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev[2][1], st));
+    ctx->ev_valid[2] = true;
+    HIP_TRY(hipEventRecord(ctx->ev[3][0], st));
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
+                       (const u64 *)d_ws, p.nseg, (int)nq, p.nq_pad, k, d_idx, d_dist);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev[3][1], st));
+    ctx->ev_valid[3] = true;
+    return FDR_OK;
+}
+
+// ---- device-pointer API ----------------------------------------------------------------------
+FDR_EXPORT int fdr_embed_dev(fdr_ctx *ctx, int64_t n_rows, const int64_t *d_indptr,
+                             const int32_t *d_indices, float *d_E, void *stream) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (n_rows > 0 && (!d_indptr || !d_E)) return fail(FDR_E_ARG, "embed: null device pointer");
+    return launch_embed(ctx, n_rows, d_indptr, d_indices, d_E, (hipStream_t)stream);
+}
+
+FDR_EXPORT int fdr_normalize_dev(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int32_t d,
+                                 float *d_Ehat, uint8_t *d_zero, void *stream) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (n_rows > 0 && (!d_E || !d_Ehat || !d_zero)) return fail(FDR_E_ARG, "normalize: null device pointer");
+    return launch_normalize(ctx, d_E, n_rows, d, d_Ehat, d_zero, (hipStream_t)stream);
+}
+
+FDR_EXPORT int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
+                           const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base,
+                           int32_t d, int32_t k, int32_t *d_idx, float *d_dist, void *d_workspace,
+                           size_t workspace_bytes, void *stream) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    return launch_knn(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
+                      d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- host-pointer API ------------------------------------------------------------------------
+static int check_csr(int64_t n_rows, const int64_t *a_indptr, const int32_t *a_indices) {
+    if (n_rows < 0 || !a_indptr) return fail(FDR_E_ARG, "embed: bad CSR (n_rows=%lld)", (long long)n_rows);
+    if (a_indptr[0] != 0 || a_indptr[n_rows] < 0) return fail(FDR_E_ARG, "embed: bad indptr");
+    if (a_indptr[n_rows] > 0 && !a_indices) return fail(FDR_E_ARG, "embed: indices is null");
+    return FDR_OK;
+}
+
+static int upload_csr(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr,
+                      const int32_t *a_indices) {
+    int rc;
+    const int64_t nnz = a_indptr[n_rows];
+    if ((rc = ctx->a_indptr.reserve((size_t)(n_rows + 1) * 8))) return rc;
+    if ((rc = ctx->a_indices.reserve((size_t)std::max<int64_t>(nnz, 1) * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->a_indptr.p, a_indptr, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nnz > 0)
+        HIP_TRY(hipMemcpyAsync(ctx->a_indices.p, a_indices, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream));
+    return FDR_OK;
+}
+
+FDR_EXPORT int fdr_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr,
+                         const int32_t *a_indices, float *E_out) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_csr(n_rows, a_indptr, a_indices))) return rc;
+    if (ctx->n_features <= 0) return fail(FDR_E_STATE, "embed: no projection loaded");
+    if (n_rows == 0) return FDR_OK;
+    if (!E_out) return fail(FDR_E_ARG, "embed: E_out is null");
+    if ((rc = upload_csr(ctx, n_rows, a_indptr, a_indices))) return rc;
+    const size_t ebytes = (size_t)n_rows * ctx->d * 4;
+    if ((rc = ctx->E.reserve(ebytes))) return rc;
+    if ((rc = launch_embed(ctx, n_rows, (const int64_t *)ctx->a_indptr.p,
+                           (const int32_t *)ctx->a_indices.p, (float *)ctx->E.p, ctx->stream)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(E_out, ctx->E.p, ebytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FDR_OK;
+}
+
+// E (device, [n,d]) -> idx/dist on the host
+static int knn_from_device_E(fdr_ctx *ctx, const float *d_E, int64_t n, int d, int k,
+                             int32_t *idx_out, float *dist_out) {
+    int rc;
+    const int dp = fdr_padded_dim(d);
+    if (dp < 0) return fail(FDR_E_ARG, "knn: dimension %d unsupported (1..%d)", d, FDR_MAX_DIM);
+    if (k < 1 || k > FDR_MAX_K) return fail(FDR_E_ARG, "knn: k=%d unsupported (1..%d)", k, FDR_MAX_K);
+    if (n < k) return fail(FDR_E_ARG, "knn: need n (%lld) >= k (%d)", (long long)n, k);
+    if (!idx_out || !dist_out) return fail(FDR_E_ARG, "knn: null output pointer");
+    if ((rc = ctx->Ehat.reserve((size_t)n * dp * 4))) return rc;
+    if ((rc = ctx->zero.reserve((size_t)n))) return rc;
+    if ((rc = ctx->idx.reserve((size_t)n * k * 4))) return rc;
+    if ((rc = ctx->dist.reserve((size_t)n * k * 4))) return rc;
+    const size_t wsb = fdr_knn_workspace_bytes(ctx, n, n, d, k);
+    if ((rc = ctx->ws.reserve(wsb))) return rc;
+    if ((rc = launch_normalize(ctx, d_E, n, d, (float *)ctx->Ehat.p, (uint8_t *)ctx->zero.p, ctx->stream)))
+        return rc;
+    if ((rc = launch_knn(ctx, (const float *)ctx->Ehat.p, (const uint8_t *)ctx->zero.p, n,
+                         (const float *)ctx->Ehat.p, (const uint8_t *)ctx->zero.p, n, 0, d, k,
+                         (int32_t *)ctx->idx.p, (float *)ctx->dist.p, ctx->ws.p, wsb, ctx->stream)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(idx_out, ctx->idx.p, (size_t)n * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dist_out, ctx->dist.p, (size_t)n * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FDR_OK;
+}
+
+FDR_EXPORT int fdr_knn(fdr_ctx *ctx, const float *E, int64_t n, int32_t d, int32_t k,
+                       int32_t *idx_out, float *dist_out) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (!E || n <= 0) return fail(FDR_E_ARG, "knn: empty input");
+    if (fdr_padded_dim(d) < 0) return fail(FDR_E_ARG, "knn: dimension %d unsupported (1..%d)", d, FDR_MAX_DIM);
+    if ((rc = ctx->E.reserve((size_t)n * d * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->E.p, E, (size_t)n * d * 4, hipMemcpyHostToDevice, ctx->stream));
+    return knn_from_device_E(ctx, (const float *)ctx->E.p, n, d, k, idx_out, dist_out);
+}
+
+FDR_EXPORT int fdr_embed_knn(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr,
+                             const int32_t *a_indices, int32_t k, int32_t *idx_out, float *dist_out,
+                             float *E_out) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_csr(n_rows, a_indptr, a_indices))) return rc;
+    if (ctx->n_features <= 0) return fail(FDR_E_STATE, "embed: no projection loaded");
+    if (n_rows <= 0) return fail(FDR_E_ARG, "embed_knn: empty input");
+    if ((rc = upload_csr(ctx, n_rows, a_indptr, a_indices))) return rc;
+    const size_t ebytes = (size_t)n_rows * ctx->d * 4;
+    if ((rc = ctx->E.reserve(ebytes))) return rc;
+    if ((rc = launch_embed(ctx, n_rows, (const int64_t *)ctx->a_indptr.p,
+                           (const int32_t *)ctx->a_indices.p, (float *)ctx->E.p, ctx->stream)))
+        return rc;
+    if (E_out) HIP_TRY(hipMemcpyAsync(E_out, ctx->E.p, ebytes, hipMemcpyDeviceToHost, ctx->stream));
+    return knn_from_device_E(ctx, (const float *)ctx->E.p, n_rows, ctx->d, k, idx_out, dist_out);
+}

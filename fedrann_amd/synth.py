@@ -1,0 +1,65 @@
+"""Synthetic ONT-like read x k-mer feature matrices.
+
+A circular "genome" of L sampled-k-mer slots; the feature id of slot s is perm[s] (jellyfish
+order is uncorrelated with position).  Read i: start U[0, L), length max(4, lognormal(ln m -
+sigma^2/2, sigma)) slots, each slot kept with probability q (sequencing error), at least one kept;
+strand flip with probability 0.5 (flipped => feature + L).  F = 2L features.  Counts for the IDF
+are U{2..2c}, shared by f and f + L.  With doubling=True row 2i is the read and row 2i+1 its
+strand mirror (the reference's behaviour, feature_extraction.py:136-140); with doubling=False one
+row per read.  No row is empty.
+"""
+import numpy as np
+
+
+def synth(R, seed=602, m=200, q=0.85, c=30, Lcap=12_500_000, sigma=0.5, doubling=False,
+          chunk=100_000):
+    """Returns dict(indptr int64, indices int32 (ascending per row), n_features, counts int64 [L],
+    names list[str], strands list[int])."""
+    rng = np.random.default_rng(seed)
+    L = int(min(max(R * m // c, 64), Lcap))
+    F = 2 * L
+    perm = rng.permutation(L).astype(np.int64)
+    counts = rng.integers(2, 2 * c + 1, size=L).astype(np.int64)
+    ip_parts, ix_parts = [np.zeros(1, dtype=np.int64)], []
+    total = 0
+    for r0 in range(0, R, chunk):
+        n = min(chunk, R - r0)
+        start = rng.integers(0, L, size=n)
+        length = np.maximum(4, rng.lognormal(np.log(m) - sigma * sigma / 2, sigma, size=n)).astype(np.int64)
+        length = np.minimum(length, L)
+        flip = rng.random(n) < 0.5
+        T = int(length.sum())
+        row = np.repeat(np.arange(n, dtype=np.int64), length)
+        first = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(length, out=first[1:])
+        off = np.arange(T, dtype=np.int64) - np.repeat(first[:-1], length)
+        keep = rng.random(T) < q
+        kept_per_row = np.bincount(row[keep], minlength=n)
+        keep[first[:-1][kept_per_row == 0]] = True  # at least one slot survives
+        row, off = row[keep], off[keep]
+        slot = (start[row] + off) % L
+        feat = perm[slot] + np.where(flip[row], L, 0)
+        if doubling:
+            mirror = np.where(feat < L, feat + L, feat - L)
+            row = np.concatenate((2 * row, 2 * row + 1))
+            feat = np.concatenate((feat, mirror))
+            nrows = 2 * n
+        else:
+            nrows = n
+        key = row * np.int64(F) + feat
+        key.sort()
+        row_s = key // np.int64(F)
+        ix_parts.append((key - row_s * np.int64(F)).astype(np.int32))
+        cnt = np.bincount(row_s, minlength=nrows)
+        ip_parts.append(total + np.cumsum(cnt))
+        total += int(cnt.sum())
+    indptr = np.concatenate(ip_parts).astype(np.int64)
+    indices = np.concatenate(ix_parts) if ix_parts else np.zeros(0, np.int32)
+    if doubling:
+        names = ["read_%d" % i for i in range(R) for _ in (0, 1)]
+        strands = [0, 1] * R
+    else:
+        names = ["read_%d" % i for i in range(R)]
+        strands = [0] * R
+    return {"indptr": indptr, "indices": indices, "n_features": F, "counts": counts,
+            "names": names, "strands": strands}

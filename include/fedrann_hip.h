@@ -1,0 +1,112 @@
+/*
+ * fedrann_hip.h -- C-ABI of libfedrann_hip.so, the MI355X (gfx950) implementation of FEDRANN's
+ * dimensionality-reduction + k-NN hot path.
+ *
+ * The reference (jzhang-dev/FEDRANN v0.5.4) has no FFI for this path: the seam is three in-process
+ * Python calls in fedrann/__main__.py (run_fedrann_pipeline):
+ *     get_precompute_matrix(...)            __main__.py:331-335  -> precompute.py:58-115
+ *     get_feature_matrix(...)               __main__.py:339-345  -> feature_extraction.py:216-292
+ *     get_neighbors_ava(...)                __main__.py:361-365  -> nearest_neighbors.py:22-55
+ * Each entry point below names the reference call it replaces.  The Python host
+ * (fedrann_amd/) keeps those three call shapes and binds this header through ctypes; the stub a
+ * reference maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; every function returns 0 on success or a negative FDR_E_*
+ *     code, and fdr_last_error() returns the message of the calling thread's last failure.
+ *   - the caller owns every buffer it passes; the library borrows pointers for the duration of the
+ *     call only.  "host" functions take host pointers and synchronise before returning; "_dev"
+ *     functions take device pointers (hipMalloc'd or a torch tensor's data_ptr()) plus a
+ *     hipStream_t passed as void*, enqueue work on that stream and return without synchronising.
+ *   - one context = one GPU; one context per process is the intended use (one process per GPU).
+ *     A context is not re-entrant: one call in flight at a time.
+ *   - all arrays are C-contiguous with exactly the element types written here.
+ */
+#ifndef FEDRANN_HIP_H
+#define FEDRANN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDR_OK 0
+#define FDR_E_ARG (-1)     /* bad argument (null pointer, size, unsupported d or k, ...) */
+#define FDR_E_HIP (-2)     /* a HIP runtime call or kernel launch failed */
+#define FDR_E_NOMEM (-4)   /* device or host allocation failed */
+#define FDR_E_STATE (-5)   /* call order (e.g. embed before a projection was loaded) */
+
+#define FDR_MAX_K 64       /* neighbours per row (self included) supported by the top-k kernel */
+#define FDR_MAX_DIM 256    /* embedding dimension supported by the k-NN kernel this round */
+
+typedef struct fdr_ctx fdr_ctx;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+int fdr_create(int device_id, fdr_ctx **out);
+int fdr_destroy(fdr_ctx *ctx);
+const char *fdr_last_error(void);
+/* "name|gcnArch|CUs|HBM bytes" of the context's device, NUL-terminated into buf. */
+int fdr_device_info(fdr_ctx *ctx, char *buf, int buflen);
+/* Padded row length (floats) of the internal normalised-embedding layout for dimension d:
+ * 128 for d <= 128, 256 for d <= 256; negative if d is unsupported. */
+int fdr_padded_dim(int d);
+
+/* ---- projection (replaces handing `precompute_matrix` to get_feature_matrix,
+ *      feature_extraction.py:226-241: P as CSR by feature, float32 data) ---------------------
+ * P is n_features x d; p_indptr int64[n_features+1], p_cols int32[nnz] in [0,d), p_vals
+ * float32[nnz].  Builds the device-side lookup tables used by the embed kernel. */
+int fdr_projection_load(fdr_ctx *ctx, int64_t n_features, int32_t d, const int64_t *p_indptr,
+                        const int32_t *p_cols, const float *p_vals);
+
+/* ---- E = A . P  (replaces process_read_chunk_optimized + the scatter loop,
+ *      feature_extraction.py:167-213, :280-290) --------------------------------------------
+ * A is the binary read x feature CSR: a_indptr int64[n_rows+1], a_indices int32[nnz], column ids
+ * ASCENDING inside each row (scipy canonical form; the host wrapper sorts).  E_out float32
+ * [n_rows, d] row-major.  E[r,c] is the sequential fp32 sum, in ascending feature order, of
+ * P[f,c] over the features f of row r -- bit-identical to the reference (golden vectors). */
+int fdr_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr, const int32_t *a_indices,
+              float *E_out);
+
+/* ---- exact cosine k-NN  (replaces NNDescent_ava().get_neighbors(E, metric="cosine",
+ *      index_n_neighbors=k, ...).neighbor_graph, nearest_neighbors.py:39-55) ---------------
+ * E float32 [n, d] (not normalised).  idx_out int32 [n,k], dist_out float32 [n,k], each row
+ * ascending by (distance, index); self is a candidate like any other row.  Canonical arithmetic
+ * (DESIGN.md "k-NN arithmetic"): rows are scaled by (float)(1/sqrt((double)chain(x,x))), the
+ * similarity is the fp32 fma chain over components 0..d-1, dist = clamp(1 - c, 0, 1), two
+ * all-zero rows are at distance 0.  Requires n >= k, 1 <= k <= FDR_MAX_K, d <= FDR_MAX_DIM. */
+int fdr_knn(fdr_ctx *ctx, const float *E, int64_t n, int32_t d, int32_t k, int32_t *idx_out,
+            float *dist_out);
+
+/* embed + k-NN with E kept in HBM between the two (what run_fedrann_pipeline does in steps 3-4,
+ * __main__.py:338-367).  E_out may be NULL. */
+int fdr_embed_knn(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr, const int32_t *a_indices,
+                  int32_t k, int32_t *idx_out, float *dist_out, float *E_out);
+
+/* ---- device-resident API (multi-GPU host, bench.py) ----------------------------------------
+ * All pointers are device pointers; work is enqueued on `stream` (a hipStream_t). */
+int fdr_embed_dev(fdr_ctx *ctx, int64_t n_rows, const int64_t *d_indptr, const int32_t *d_indices,
+                  float *d_E, void *stream);
+/* E [n_rows,d] -> Ehat [n_rows, fdr_padded_dim(d)] in the kernel's internal layout (normalised,
+ * zero padded, components permuted inside groups of 8) + zero-row flags uint8[n_rows]. */
+int fdr_normalize_dev(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int32_t d, float *d_Ehat,
+                      uint8_t *d_zero, void *stream);
+/* bytes of scratch fdr_knn_dev needs for (nq queries, nt targets, k). */
+size_t fdr_knn_workspace_bytes(fdr_ctx *ctx, int64_t nq, int64_t nt, int32_t d, int32_t k);
+/* k-NN of nq query rows against nt target rows, both in the Ehat layout.  Neighbour indices are
+ * target row numbers + t_base.  Rows of a row-sharded run: queries = the rank's shard, targets =
+ * the all-gathered Ehat of every rank. */
+int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
+                const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int32_t d,
+                int32_t k, int32_t *d_idx, float *d_dist, void *d_workspace, size_t workspace_bytes,
+                void *stream);
+/* Duration in ms of the most recent kernel of each kind launched through this context
+ * (hipEvent pair recorded on the launch stream); synchronises on the stop event.
+ * which: 0 = embed, 1 = normalize, 2 = knn tile kernel, 3 = knn merge. */
+int fdr_last_kernel_ms(fdr_ctx *ctx, int which, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEDRANN_HIP_H */

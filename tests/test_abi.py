@@ -1,0 +1,52 @@
+"""The C-ABI library: builds for gfx950, loads, exports every symbol of include/fedrann_hip.h, and
+fails loudly without a GPU (no compute calls here)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from fedrann_amd import _lib, build
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_library()
+    return _lib.load_library()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "fedrann_hip.h")).read()
+    declared = set(re.findall(r"\b(fdr_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_constants_match_header():
+    hdr = open(os.path.join(ROOT, "include", "fedrann_hip.h")).read()
+    assert int(re.search(r"#define FDR_MAX_K (\d+)", hdr).group(1)) == _lib.FDR_MAX_K
+    assert int(re.search(r"#define FDR_MAX_DIM (\d+)", hdr).group(1)) == _lib.FDR_MAX_DIM
+
+
+def test_padded_dim_needs_no_gpu(lib):
+    assert lib.fdr_padded_dim(1) == 128 and lib.fdr_padded_dim(128) == 128
+    assert lib.fdr_padded_dim(129) == 256 and lib.fdr_padded_dim(256) == 256
+    assert lib.fdr_padded_dim(257) < 0 and lib.fdr_padded_dim(0) < 0
+
+
+def test_no_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.FedrannHipError) as e:
+        _lib.Context(0)
+    assert "fdr_create" in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fedrann_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the CPU oracle's chain_dot()", ""), os.path.join(dirpath, f)

@@ -1,0 +1,162 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle and the reference's golden
+vectors.  Integer / index results and fp32 bit patterns must be IDENTICAL; the k-NN distances are
+additionally checked within 1e-5 as BASELINE.json's north_star words it."""
+import numpy as np
+import pytest
+
+from conftest import golden_embed_case
+from fedrann_amd import _lib
+from fedrann_amd.precompute import build_precompute_matrix
+from fedrann_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _assert_knn_equal(got, want):
+    gi, gd = got
+    wi, wd = want
+    assert np.array_equal(gi, wi), "neighbour indices / ranks differ in %d of %d cells" % (
+        int((gi != wi).sum()), gi.size)
+    assert np.abs(gd - wd).max() <= 1e-5
+    assert np.array_equal(_bits(gd), _bits(wd)), "distance bit patterns differ"
+
+
+# ---- E = A . P -------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["tiny", "mid"])
+def test_embed_matches_reference_golden(ctx, tag):
+    indptr, indices, P, F, d, E_bits = golden_embed_case(tag)
+    # rows arrive in kmer_searcher's arbitrary order; the ABI wants ascending columns per row
+    from fedrann_amd.feature_extraction import canonical_csr
+    ip, ix = canonical_csr(indptr, indices, F)
+    ctx.projection_load(P[0], P[1], P[2], F, d)
+    E = ctx.embed(ip, ix)
+    assert np.array_equal(_bits(E), E_bits)
+
+
+@pytest.mark.parametrize("R,d,m", [(3000, 128, 200), (1500, 64, 50), (800, 200, 120), (500, 256, 400)])
+def test_embed_matches_oracle_on_synthetic(ctx, oracle, R, d, m):
+    s = synth(R, seed=R + d, m=m)
+    P = build_precompute_matrix(s["counts"], d)
+    ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], d)
+    E = ctx.embed(s["indptr"], s["indices"])
+    want = oracle.embed(s["indptr"], s["indices"], (P.indptr, P.indices, P.data), s["n_features"], d)
+    assert np.array_equal(_bits(E), _bits(want))
+
+
+def test_embed_empty_rows_and_long_rows(ctx, oracle):
+    _, _, P, F, d, _ = golden_embed_case("mid")
+    rng = np.random.default_rng(4)
+    rows = [np.sort(rng.choice(F, size=n, replace=False)) for n in (0, 1, 63, 64, 65, 0, 5000, 129, 0)]
+    indptr, indices = oracle.rows_to_csr(rows)
+    ctx.projection_load(P[0], P[1], P[2], F, d)
+    E = ctx.embed(indptr, indices.astype(np.int32))
+    want = oracle.embed(indptr, indices, P, F, d)
+    assert np.array_equal(_bits(E), _bits(want))
+    assert not E[0].any() and not E[5].any() and not E[8].any()
+
+
+def test_embed_dense_projection_rows(ctx, oracle):
+    # a projection where most features have several entries: exercises the multi-entry loop
+    rng = np.random.default_rng(10)
+    F, d = 4096, 128
+    import scipy.sparse as sp
+    P = sp.random(F, d, density=0.05, format="csr", dtype=np.float32, random_state=3,
+                  data_rvs=lambda n: rng.standard_normal(n).astype(np.float32))
+    P.sort_indices()
+    rows = [np.sort(rng.choice(F, size=int(n), replace=False)) for n in rng.integers(1, 300, size=500)]
+    indptr, indices = oracle.rows_to_csr(rows)
+    ctx.projection_load(P.indptr, P.indices, P.data, F, d)
+    E = ctx.embed(indptr, indices.astype(np.int32))
+    want = oracle.embed(indptr, indices, (P.indptr, P.indices, P.data), F, d)
+    assert np.array_equal(_bits(E), _bits(want))
+
+
+# ---- k-NN ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,k", [(2000, 128, 20), (777, 128, 20), (3000, 64, 20), (1200, 200, 50),
+                                   (900, 256, 50), (300, 128, 1), (513, 100, 64), (64, 128, 64),
+                                   (33, 7, 33)])
+def test_knn_dense_random_matches_oracle(ctx, oracle, n, d, k):
+    E = np.random.default_rng(n + d + k).standard_normal((n, d)).astype(np.float32)
+    _assert_knn_equal(ctx.knn(E, k), oracle.knn(E, k))
+
+
+def test_knn_multi_segment_matches_oracle(ctx, oracle):
+    # 20 000 rows -> several target segments per query block + the merge kernel
+    E = np.random.default_rng(77).standard_normal((20000, 128)).astype(np.float32)
+    _assert_knn_equal(ctx.knn(E, 20), oracle.knn(E, 20))
+
+
+def test_knn_on_reference_embedding_with_ties_and_zero_rows(ctx, oracle):
+    *_, E_bits = golden_embed_case("mid")
+    E = E_bits.view(np.float32)
+    assert (np.abs(E).sum(1) == 0).sum() > 0  # the golden matrix has all-zero rows
+    for k in (20, 50):
+        _assert_knn_equal(ctx.knn(E, k), oracle.knn(E, k))
+
+
+def test_knn_heavy_ties(ctx, oracle):
+    rng = np.random.default_rng(9)
+    base = rng.standard_normal((50, 128)).astype(np.float32)
+    onehot = np.zeros((400, 128), np.float32)
+    onehot[np.arange(400), rng.integers(0, 6, size=400)] = rng.choice([-2.0, 3.0], size=400)
+    E = np.concatenate([base, base, np.zeros((70, 128), np.float32), onehot, base[:25],
+                        np.zeros((3, 128), np.float32)])
+    E = E[rng.permutation(E.shape[0])]
+    for k in (20, 50):
+        _assert_knn_equal(ctx.knn(E, k), oracle.knn(E, k))
+
+
+def test_knn_synthetic_pipeline_config2_shape_small(ctx, oracle):
+    # the bench workload's generator at a size the oracle finishes in seconds
+    s = synth(6000, seed=602)
+    P = build_precompute_matrix(s["counts"], 128)
+    ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], 128)
+    idx, dist, E = ctx.embed_knn(s["indptr"], s["indices"], 20, return_embedding=True)
+    want_E = oracle.embed(s["indptr"], s["indices"], (P.indptr, P.indices, P.data), s["n_features"], 128)
+    assert np.array_equal(_bits(E), _bits(want_E))
+    _assert_knn_equal((idx, dist), oracle.knn(want_E, 20))
+    _assert_knn_equal(ctx.knn(E, 20), (idx, dist))  # fused == separate
+
+
+def test_knn_full_size_properties_and_sampled_oracle(ctx, oracle):
+    """BASELINE config 2 (100k rows, d=128, k=20): size-independent properties over the whole
+    result + exact oracle agreement on a sample of query rows."""
+    s = synth(100_000, seed=602)
+    P = build_precompute_matrix(s["counts"], 128)
+    ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], 128)
+    idx, dist, E = ctx.embed_knn(s["indptr"], s["indices"], 20, return_embedding=True)
+    n = E.shape[0]
+    key = _bits(dist).astype(np.uint64) << np.uint64(32) | idx.astype(np.uint64)
+    assert np.all(key[:, 1:] > key[:, :-1])  # strictly ascending (dist, idx), no repeats
+    assert idx.min() >= 0 and idx.max() < n and dist.min() >= 0 and dist.max() <= 1
+    nonzero = np.abs(E).sum(1) > 0
+    self_found = (idx == np.arange(n)[:, None]).any(1)
+    assert np.all(self_found[nonzero])  # a non-zero row always finds itself (distance ~ 0)
+    assert np.all(dist[nonzero, 0] <= 2e-7)
+    idx2, dist2 = ctx.knn(E, 20)  # idempotence: same answer from the separate entry point
+    assert np.array_equal(idx, idx2) and np.array_equal(_bits(dist), _bits(dist2))
+    rows = np.random.default_rng(1).choice(n, size=384, replace=False)
+    Eh, _, zero = oracle.normalize(E)
+    wi, wd = oracle.knn_normalized(Eh[rows], zero[rows], Eh, zero, 20)
+    _assert_knn_equal((idx[rows], dist[rows]), (wi, wd))
+
+
+# ---- error behaviour -----------------------------------------------------------------------------
+def test_errors_are_raised_not_swallowed(ctx):
+    E = np.zeros((10, 16), np.float32)
+    with pytest.raises(_lib.FedrannHipError):
+        ctx.knn(E, 11)  # k > n
+    with pytest.raises(_lib.FedrannHipError):
+        ctx.knn(E, 0)
+    with pytest.raises(_lib.FedrannHipError):
+        ctx.knn(np.zeros((100, 300), np.float32), 5)  # d > FDR_MAX_DIM
+    with pytest.raises(_lib.FedrannHipError):
+        ctx.knn(np.zeros((100, 16), np.float32), 65)  # k > FDR_MAX_K
+    fresh = _lib.Context(0)
+    with pytest.raises(_lib.FedrannHipError):
+        fresh.embed(np.array([0, 1], np.int64), np.array([0], np.int32))  # no projection loaded
+    fresh.close()

@@ -1,0 +1,191 @@
+"""Host-side logic of fedrann_amd (no GPU): projection builder, output.bin / npz readers, TSV
+writer, synthetic generator -- each against the reference's golden vectors and/or the oracle."""
+import hashlib
+import io
+import json
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import golden, golden_embed_case
+from fedrann_amd import feature_extraction as fx
+from fedrann_amd import precompute as pc
+from fedrann_amd.__main__ import build_parser, get_output_dataframe
+from fedrann_amd.synth import synth
+
+
+def _write_fasta(path, counts, crlf=False):
+    nl = "\r\n" if crlf else "\n"
+    with open(path, "w", newline="") as f:
+        for c in counts:
+            f.write(">%d%s%s%s" % (int(c), nl, "ACGTACGT", nl))
+
+
+def _write_output_bin(path, names, rows):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sB3sQ", b"KMER", 1, b"\0\0\0", len(names)))
+        for n, r in zip(names, rows):
+            nb = n if isinstance(n, bytes) else n.encode()
+            f.write(struct.pack("<H", len(nb)) + nb + struct.pack("<I", len(r)))
+            f.write(struct.pack("<%dQ" % len(r), *[int(i) for i in r]))
+
+
+@pytest.mark.parametrize("tag", ["tiny", "mid"])
+def test_get_precompute_matrix_matches_reference(tmp_path, tag):
+    g = np.load(golden("precompute_%s.npz" % tag))
+    fa = tmp_path / "lib.fasta"
+    _write_fasta(fa, g["counts"])
+    P, F = pc.get_precompute_matrix(n_components=int(g["d"]), counter_file=str(fa),
+                                    n_features=2 * len(g["counts"]))
+    assert F == 2 * len(g["counts"]) and P.shape == (F, int(g["d"])) and P.dtype == np.float32
+    assert np.array_equal(P.indptr, g["indptr"])
+    assert np.array_equal(P.indices, g["indices"])
+    assert np.array_equal(P.data.view(np.uint32), g["data_bits"])
+
+
+def test_precompute_big_digest_and_oracle(oracle):
+    meta = json.load(open(golden("precompute_big.json")))
+    counts = np.random.default_rng(11).integers(2, 61, size=meta["L"]).astype(np.int64)
+    P = pc.build_precompute_matrix(counts, meta["d"])
+    h = hashlib.sha256()
+    for a in (P.indptr.astype(np.int64), P.indices.astype(np.int32), P.data.view(np.uint32)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert h.hexdigest() == meta["sha256_indptr_i64_indices_i32_data_f32"]
+
+
+def test_read_kmer_counts_variants(tmp_path):
+    counts = [2, 5, 31, 1000000007, 7]
+    a = tmp_path / "a.fasta"
+    _write_fasta(a, counts)
+    assert pc.read_kmer_counts(str(a)).tolist() == counts
+    b = tmp_path / "b.fasta"
+    _write_fasta(b, counts, crlf=True)
+    assert pc.read_kmer_counts(str(b)).tolist() == counts
+    c = tmp_path / "c.fasta"  # no trailing newline, header followed by two k-mers
+    c.write_text(">3\nAAAA\nCCCC\n>9\nGGGG")
+    assert pc.read_kmer_counts(str(c)).tolist() == [3, 3, 9]
+    gen = list(pc.kmer_count_generator(str(c), 3))
+    assert gen == [(0, 3), (3, 3), (1, 3), (4, 3), (2, 9), (5, 9)]
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">x1\nAAAA\n")
+    with pytest.raises(ValueError):
+        pc.read_kmer_counts(str(bad))
+    (tmp_path / "e.fasta").write_text("")
+    assert pc.read_kmer_counts(str(tmp_path / "e.fasta")).size == 0
+
+
+def test_output_bin_reader_matches_oracle(tmp_path, oracle):
+    rng = np.random.default_rng(2)
+    L = 500
+    names = ["r%d/x" % i for i in range(60)] + [b"bad\xff\xfename", "", "dup", "dup"]
+    rows = [rng.choice(2 * L, size=int(rng.integers(0, 40)), replace=False) for _ in names]
+    p = tmp_path / "output.bin"
+    _write_output_bin(p, names, rows)
+    o_names, o_strands, o_rows = oracle.parse_output_bin(str(p), L)
+    n2, s2 = fx.get_metadata(str(p), 2 * L)
+    assert n2 == o_names and s2 == o_strands
+    gen = list(fx.parse_kmer_searcher_output(str(p), L))
+    assert [g[0] for g in gen] == o_names and [g[2] for g in gen] == o_strands
+    assert [list(g[1]) for g in gen] == o_rows
+    indptr, indices, n3, s3 = fx.build_feature_csr(str(p), 2 * L)
+    assert n3 == o_names and s3 == o_strands
+    for r, want in enumerate(o_rows):
+        assert indices[indptr[r]:indptr[r + 1]].tolist() == sorted(want)
+
+
+def test_output_bin_errors(tmp_path):
+    p = tmp_path / "x.bin"
+    p.write_bytes(b"KME")
+    with pytest.raises(ValueError):
+        fx.read_kmer_searcher_output(str(p))
+    p.write_bytes(struct.pack("<4sB3sQ", b"XXXX", 1, b"\0\0\0", 0))
+    with pytest.raises(ValueError):
+        fx.read_kmer_searcher_output(str(p))
+    p.write_bytes(struct.pack("<4sB3sQ", b"KMER", 2, b"\0\0\0", 0))
+    with pytest.raises(ValueError):
+        fx.read_kmer_searcher_output(str(p))
+    p.write_bytes(struct.pack("<4sB3sQ", b"KMER", 1, b"\0\0\0", 1) + struct.pack("<H", 2) + b"ab"
+                  + struct.pack("<I", 3) + struct.pack("<2Q", 1, 2))
+    with pytest.raises(ValueError):
+        fx.read_kmer_searcher_output(str(p))
+    p.write_bytes(struct.pack("<4sB3sQ", b"KMER", 1, b"\0\0\0", 0))
+    names, indptr, idx = fx.read_kmer_searcher_output(str(p))
+    assert names == [] and indptr.tolist() == [0] and idx.size == 0
+
+
+def test_canonical_csr_checks():
+    ip, ix = fx.canonical_csr([0, 3, 3, 5], [9, 2, 4, 7, 1], 10)
+    assert ix.tolist() == [2, 4, 9, 1, 7] and ix.dtype == np.int32 and ip.dtype == np.int64
+    with pytest.raises(ValueError):
+        fx.canonical_csr([0, 2], [3, 10], 10)
+    with pytest.raises(ValueError):
+        fx.canonical_csr([0, 2], [3, 3], 10)
+    with pytest.raises(ValueError):
+        fx.canonical_csr([0, 3], [1, 2], 10)
+
+
+def test_feature_matrix_npz_roundtrip_is_scipy_format(tmp_path):
+    import scipy.sparse as sp
+    s = synth(300, seed=5, m=40)
+    p = tmp_path / "feature_matrix.npz"
+    fx.save_feature_matrix_npz(str(p), s["indptr"], s["indices"], s["n_features"])
+    A = sp.csr_matrix((np.ones(s["indices"].size, np.int8), s["indices"], s["indptr"].astype(np.int32)),
+                      shape=(300, s["n_features"]))
+    q = tmp_path / "ref.npz"
+    sp.save_npz(str(q), A)
+    assert p.read_bytes() == q.read_bytes()  # byte-identical to scipy.sparse.save_npz
+    ip, ix, F = fx.load_feature_matrix_npz(str(p))
+    assert F == s["n_features"] and np.array_equal(ip, s["indptr"]) and np.array_equal(ix, s["indices"])
+
+
+@pytest.mark.parametrize("tag", ["overlaps_edge", "overlaps_rand"])
+def test_overlaps_writer_is_byte_identical(tag):
+    g = np.load(golden(tag + ".npz"))
+    df = get_output_dataframe(g["indices"], g["dist_bits"].view(np.float32), list(g["names"]),
+                              [int(s) for s in g["strands"]])
+    buf = io.StringIO()
+    df.to_csv(buf, sep="\t", index=False)
+    assert buf.getvalue() == open(golden(tag + ".tsv"), newline="").read()
+    assert df["distance"].dtype == np.float32 and df["neighbor_rank"].dtype == np.int64
+
+
+def test_overlaps_writer_equals_oracle_loop(oracle):
+    rng = np.random.default_rng(8)
+    n, k = 57, 9
+    idx = rng.integers(0, n, size=(n, k)).astype(np.int32)
+    idx[::3, 0] = np.arange(n)[::3]
+    dist = np.sort(rng.random((n, k)).astype(np.float32), axis=1)
+    names = ["n%d" % (i // 2) for i in range(n)]
+    strands = [i % 2 for i in range(n)]
+    df = get_output_dataframe(idx, dist, names, strands)
+    buf = io.StringIO()
+    df.to_csv(buf, sep="\t", index=False)
+    assert buf.getvalue() == oracle.overlaps_tsv(idx, dist, names, strands)
+
+
+def test_synth_properties():
+    s = synth(2000, seed=602, m=60)
+    ip, ix, F = s["indptr"], s["indices"], s["n_features"]
+    assert ip[0] == 0 and ip[-1] == ix.size and len(ip) == 2001
+    assert np.all(np.diff(ip) >= 1)  # no empty row
+    rows = np.repeat(np.arange(2000), np.diff(ip))
+    same = rows[1:] == rows[:-1]
+    assert np.all(ix[1:][same] > ix[:-1][same])  # strictly ascending inside a row
+    assert ix.min() >= 0 and ix.max() < F and s["counts"].size == F // 2
+    s2 = synth(2000, seed=602, m=60)
+    assert np.array_equal(s2["indices"], ix)
+    d = synth(50, seed=1, m=30, doubling=True)
+    L = d["n_features"] // 2
+    for i in range(50):
+        a = d["indices"][d["indptr"][2 * i]:d["indptr"][2 * i + 1]].astype(np.int64)
+        b = d["indices"][d["indptr"][2 * i + 1]:d["indptr"][2 * i + 2]].astype(np.int64)
+        assert sorted(np.where(a < L, a + L, a - L).tolist()) == b.tolist()
+
+
+def test_cli_flags_match_reference_defaults():
+    a = build_parser().parse_args(["-o", "out", "--feature-matrix", "x.npz", "--kmer-counts", "c.npy"])
+    assert (a.kmer_size, a.kmer_sample_fraction, a.kmer_min_multiplicity) == (16, 0.005, 2)
+    assert (a.threads, a.chunk_size, a.embedding_dimension) == (1, 1000, 500)
+    assert (a.nndescent_n_trees, a.nndescent_n_neighbors, a.seed) == (300, 50, 356115)
+    assert not a.save_feature_matrix and not a.keep_intermediates and not a.mprof
