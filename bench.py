@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- read-pairs/s of the FEDRANN hot path (embed -> normalise -> all-pairs cosine k-NN).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--dim D] [--knn k]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over the whole synthetic read set: every rank embeds and
+normalises its row block, the normalised embeddings are all-gathered (N > 1), and every rank
+searches its rows against all targets.  Default workload = BASELINE.json configs[1]: 100k synthetic
+ONT reads, 128-dim projection, k-NN = 20.  Inputs (the read x k-mer CSR and the projection
+tables) are resident in HBM before the timed region; results stay in HBM.  The total work is the
+same for every N (strong scaling): value = R * k * steps / time.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (knn_tile, fp32 MFMA);
+`cpu_baseline` times this repo's CPU oracle (a port of the path, not the reference's pynndescent,
+which is not installed) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--reads", type=int, default=100_000, help="rows of the feature matrix")
+    p.add_argument("--dim", type=int, default=128)
+    p.add_argument("--knn", type=int, default=20)
+    p.add_argument("--seed", type=int, default=602)
+    p.add_argument("--cpu-baseline-seconds", type=float, default=15.0,
+                   help="target CPU time of the cpu_baseline sample (0 = skip)")
+    p.add_argument("--doubling", action="store_true", help="fwd/rev row doubling (2 rows per read)")
+    return p.parse_args()
+
+
+def cpu_baseline(s, P, d, k, target_seconds):
+    """Time the CPU oracle on a bounded sample: embed + normalise ALL rows (they are the targets),
+    then k-NN for as many query rows as fit the time budget; extrapolate linearly in queries."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = O.lib().orc_num_threads()
+    n = len(s["indptr"]) - 1
+    t0 = time.perf_counter()
+    E = O.embed(s["indptr"], s["indices"], (P.indptr, P.indices, P.data), s["n_features"], d)
+    t_embed = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    Eh, _, zero = O.normalize(E)
+    t_norm = time.perf_counter() - t0
+    probe = min(n, 256)
+    t0 = time.perf_counter()
+    O.knn_normalized(Eh[:probe], zero[:probe], Eh, zero, k)
+    t_probe = time.perf_counter() - t0
+    nq = int(min(n, max(probe, target_seconds / max(t_probe / probe, 1e-9))))
+    nq = max(64, nq // 64 * 64) if n >= 64 else n
+    t0 = time.perf_counter()
+    O.knn_normalized(Eh[:nq], zero[:nq], Eh, zero, k)
+    t_knn = time.perf_counter() - t0
+    est_total = t_embed + t_norm + t_knn * n / nq
+    return {
+        "value": n * k / est_total, "unit": "read-pairs/s", "cores": cores, "kind": "port",
+        "sample": ("oracle/fedrann_oracle.c (exact fp32 cosine k-NN, AVX2+OpenMP): embed+normalise all "
+                   "%d rows (%.2fs+%.2fs), k-NN of %d of %d query rows vs all targets in %.2fs, "
+                   "extrapolated x%.1f in queries" % (n, t_embed, t_norm, nq, n, t_knn, n / nq)),
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from fedrann_amd import _lib
+    from fedrann_amd.distributed import HipEngine, ShardedPipeline, local_csr
+    from fedrann_amd.precompute import build_precompute_matrix
+    from fedrann_amd.synth import synth
+
+    R, d, k = args.reads, args.dim, args.knn
+    s = synth(R, seed=args.seed, doubling=args.doubling)
+    n = len(s["indptr"]) - 1
+    P = build_precompute_matrix(s["counts"], d)
+
+    ctx = _lib.Context(local_rank)
+    ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], d)
+    engine = HipEngine(ctx, device)
+    pipe = ShardedPipeline(engine, n, d, k, rank=rank, world_size=world, device=device)
+    ip, ix = local_csr(s["indptr"], s["indices"], pipe.lo, pipe.hi)
+    d_ip = torch.from_numpy(ip).to(device)
+    d_ix = torch.from_numpy(ix).to(device)
+    nloc = pipe.hi - pipe.lo
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        out = pipe.step(d_ip, d_ix)
+    barrier()
+    ctx.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pipe.step(d_ip, d_ix)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = {}
+    for i, name in enumerate(_lib.KERNELS):
+        cnt, ms = ctx.timing_read(i)
+        kernel_ms[name] = ms / max(cnt, 1)
+    ctx.timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on the last step's result (not timed): self is its own nearest neighbour
+    idx = out[0][: min(nloc, 4096)].cpu().numpy()
+    dst = out[1][: min(nloc, 4096)].cpu().numpy()
+    E = out[2][: min(nloc, 4096)].cpu().numpy()
+    nz = np.abs(E).sum(1) > 0
+    rows = np.arange(pipe.lo, pipe.lo + idx.shape[0])
+    ok = bool(np.all((idx == rows[:, None]).any(1)[nz])) and bool(np.all(np.diff(dst, axis=1) >= 0))
+    zero_frac = float(1.0 - nz.mean()) if nz.size else 0.0
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n * k * args.steps / elapsed
+        # roofline of the dominant kernel: all ordered (query, target) pairs of this rank, 2*d flop each
+        flops = 2.0 * nloc * n * d
+        knn_ms = kernel_ms["knn_tile"]
+        achieved = flops / (knn_ms * 1e-3) / 1e12 if knn_ms > 0 else 0.0
+        nnz_loc = int(ix.size)
+        embed_bytes = 4.0 * nnz_loc + 8.0 * nloc + 4.0 * nloc * d
+        result = {
+            "metric": "read-pairs/sec (overlap candidates)", "value": value, "unit": "read-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%d synthetic ONT reads (%d rows%s), %d-dim projection, k-NN=%d, "
+                                   "row-sharded over %d GPU(s)" % (R, n, ", fwd/rev doubled" if args.doubling else "",
+                                                                  d, k, world),
+                       "reads": R, "rows": n, "dim": d, "knn": k, "n_features": int(s["n_features"]),
+                       "nnz": int(s["indptr"][-1]), "parallelism": "rows/%d + all-gather" % world,
+                       "zero_row_fraction_sample": zero_frac, "self_check": ok},
+            "roofline": {"kernel": "knn_tile_kernel<%d>" % ctx.padded_dim(d), "bound": "mfma",
+                         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "flops_per_launch": flops, "avg_launch_ms": knn_ms},
+            "kernels_ms": kernel_ms,
+            "embed_roofline": {"bound": "hbm", "achieved": embed_bytes / (kernel_ms["embed_csr"] * 1e-3) / 1e9
+                               if kernel_ms["embed_csr"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "bytes_per_launch": embed_bytes},
+        }
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            result["cpu_baseline"] = cpu_baseline(s, P, d, k, args.cpu_baseline_seconds)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

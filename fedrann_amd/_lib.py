@@ -14,9 +14,10 @@ LIB_PATH = os.path.join(HERE, "libfedrann_hip.so")
 SYMBOLS = (
     "fdr_create", "fdr_destroy", "fdr_last_error", "fdr_device_info", "fdr_padded_dim",
     "fdr_projection_load", "fdr_embed", "fdr_knn", "fdr_embed_knn", "fdr_embed_dev",
-    "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_last_kernel_ms",
+    "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_timing", "fdr_timing_read",
 )
 FDR_MAX_K = 64
+KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge")
 FDR_MAX_DIM = 256
 
 
@@ -53,7 +54,9 @@ def load_library():
     L.fdr_knn_workspace_bytes.argtypes = [vp, i64, i64, i32, i32]
     L.fdr_knn_workspace_bytes.restype = sz
     L.fdr_knn_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, vp, sz, vp]
-    L.fdr_last_kernel_ms.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    L.fdr_timing.argtypes = [vp, ctypes.c_int]
+    L.fdr_timing_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                  ctypes.POINTER(ctypes.c_float)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("fdr_last_error", "fdr_knn_workspace_bytes"):
@@ -124,11 +127,15 @@ class Context:
             raise FedrannHipError("embedding dimension %d unsupported (1..%d)" % (d, FDR_MAX_DIM))
         return dp
 
-    def last_kernel_ms(self, which):
-        ms = ctypes.c_float()
-        self._check(self._L.fdr_last_kernel_ms(self._h, int(which), ctypes.byref(ms)),
-                    "fdr_last_kernel_ms")
-        return float(ms.value)
+    def timing(self, enable):
+        self._check(self._L.fdr_timing(self._h, 1 if enable else 0), "fdr_timing")
+
+    def timing_read(self, which):
+        """(launch count, total ms) of kernel kind `which` since the last read; KERNELS names them."""
+        n, ms = ctypes.c_int(), ctypes.c_float()
+        self._check(self._L.fdr_timing_read(self._h, int(which), ctypes.byref(n), ctypes.byref(ms)),
+                    "fdr_timing_read")
+        return int(n.value), float(ms.value)
 
     # -- host-pointer API -----------------------------------------------------------------------
     def projection_load(self, p_indptr, p_cols, p_vals, n_features, d):

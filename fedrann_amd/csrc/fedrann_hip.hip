@@ -190,17 +190,28 @@ __device__ __forceinline__ float dist_from_sim(float c) {
     return dv;
 }
 
+// zero-row byte flags -> one bit per target row (bit r of word w = row 32w + r)
+__global__ __launch_bounds__(256) void pack_zero_bits_kernel(const unsigned char *__restrict__ zero,
+                                                             int n, unsigned *__restrict__ bits) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool z = i < n && zero[i] != 0;
+    const u64 m = __ballot(z);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 && i < n) bits[i >> 5] = (unsigned)m;
+    if (lane == 32 && i < n) bits[i >> 5] = (unsigned)(m >> 32);
+}
+
 template <int DP>
 __global__ __launch_bounds__(512, (DP <= 128 ? 4 : 2)) void knn_tile_kernel(
     const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
-    const float *__restrict__ Th, const unsigned char *__restrict__ tzero, int nt, int t_base,
+    const float *__restrict__ Th, const unsigned *__restrict__ tzbits, int nt, int t_base,
     int seg_len, int K, int nq_pad, u64 *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int TILE_FLOATS = 32 * DP;
-    constexpr int SLOTS = DP / 4;  // 16-byte slots per row
-    float *tiles = reinterpret_cast<float *>(smem);                       // 2 * TILE_FLOATS
-    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * TILE_FLOATS * 4);     // K * 256
-    unsigned char *tzf = smem + 2 * TILE_FLOATS * 4 + (size_t)K * 256 * 8;  // 2 * 32
+    constexpr int NCH = DP / 128;            // 128-component K-chunks per tile
+    constexpr int STAGE_FLOATS = 32 * 128;   // one stage = 32 target rows x 128 components (16 KB)
+    constexpr int SLOTS = 32;                // 16-byte slots per staged row
+    float *stages = reinterpret_cast<float *>(smem);                    // 2 stages
+    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_FLOATS * 4);  // K * 256 keys
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -209,6 +220,7 @@ __global__ __launch_bounds__(512, (DP <= 128 ? 4 : 2)) void knn_tile_kernel(
     const int qg = blockIdx.x * 256 + ql;
     const int qrow = qg < nq ? qg : nq - 1;
     const bool qz = qzero[qrow] != 0;
+    const bool any_qz = __any(qz);
 
     // queries: this lane's B fragments for all DP/2 K-steps
     float b[DP / 2];
@@ -227,142 +239,147 @@ __global__ __launch_bounds__(512, (DP <= 128 ? 4 : 2)) void knn_tile_kernel(
     float tau = __builtin_inff();
     int taupos = 0;
 
-    const int t_begin = blockIdx.y * seg_len;
+    const int t_begin = blockIdx.y * seg_len;  // multiple of 32
     const int t_end = min(nt, t_begin + seg_len);
     const int ntiles = (t_end - t_begin + 31) >> 5;
+    const int nstages = ntiles * NCH;
 
-    constexpr int LPT = TILE_FLOATS / 4 / 512;  // 16-byte loads per thread per tile
-    f32x4 stage[LPT];
-    unsigned char stage_flag = 0;
-
-    auto load_tile = [&](int t) {
+    // staging: 16 KB per stage = two 16-byte loads per thread; rows are XOR-swizzled by slot so
+    // that the MFMA loop's ds_read_b128 (32 rows x one slot) is bank-conflict free
+    f32x4 stage[2];
+    auto load_stage = [&](int it) {
+        const int t = it / NCH, ch = it % NCH;
         const int trow0 = t_begin + t * 32;
 #pragma unroll
-        for (int u = 0; u < LPT; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int f4 = tid + 512 * u;
-            const int row = f4 / SLOTS, slot = f4 % SLOTS;
+            const int row = f4 >> 5, slot = f4 & 31;
             const int trow = trow0 + row;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (trow < t_end) v = reinterpret_cast<const f32x4 *>(Th + (size_t)trow * DP)[slot];
+            if (trow < t_end)
+                v = reinterpret_cast<const f32x4 *>(Th + (size_t)trow * DP)[ch * SLOTS + slot];
             stage[u] = v;
         }
-        if (tid < 32) {
-            const int trow = trow0 + tid;
-            stage_flag = trow < t_end ? tzero[trow] : 0;
-        }
     };
-    auto store_tile = [&](int buf) {
-        f32x4 *tb = reinterpret_cast<f32x4 *>(tiles + buf * TILE_FLOATS);
+    auto store_stage = [&](int buf) {
+        f32x4 *sb = reinterpret_cast<f32x4 *>(stages + buf * STAGE_FLOATS);
 #pragma unroll
-        for (int u = 0; u < LPT; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int f4 = tid + 512 * u;
-            const int row = f4 / SLOTS, slot = f4 % SLOTS;
-            tb[row * SLOTS + (slot ^ (row & 15))] = stage[u];
+            const int row = f4 >> 5, slot = f4 & 31;
+            sb[row * SLOTS + (slot ^ (row & 15))] = stage[u];
         }
-        if (tid < 32) tzf[buf * 32 + tid] = stage_flag;
     };
 
-    if (ntiles > 0) {
-        load_tile(0);
-        store_tile(0);
+    if (nstages > 0) {
+        load_stage(0);
+        store_stage(0);
     }
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) load_tile(t + 1);
-
-        // ---- 32 targets x 32 queries x DP: DP/2 chained MFMAs ----
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        {
-            const f32x4 *tb = reinterpret_cast<const f32x4 *>(tiles + buf * TILE_FLOATS) + j * SLOTS;
-            const int sw = j & 15;
 #pragma unroll
-            for (int g = 0; g < DP / 8; ++g) {
-                const f32x4 a = tb[(2 * g + h) ^ sw];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * g + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * g + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * g + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * g + 3], acc, 0, 0, 0);
-            }
-        }
-        // acc[r] = <query j, target row (r&3) + 8*(r>>2) + 4*h of this tile>
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int it = t * NCH + ch;
+            const int buf = it & 1;
+            if (it + 1 < nstages) load_stage(it + 1);
 
-        if (__any(qz)) {  // an all-zero query is at distance 0 from all-zero targets, 1 from the rest
-            if (qz) {
+            // ---- 32 targets x 32 queries x 128 components: 64 chained MFMAs ----
+            {
+                const f32x4 *sb = reinterpret_cast<const f32x4 *>(stages + buf * STAGE_FLOATS) + j * SLOTS;
+                const int sw = j & 15;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[r] = tzf[buf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] ? 1.0f : 0.0f;
+                for (int g = 0; g < 16; ++g) {
+                    const f32x4 a = sb[(2 * g + h) ^ sw];
+                    const int bb = 64 * ch + 4 * g;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[bb + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[bb + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[bb + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[bb + 3], acc, 0, 0, 0);
+                }
             }
-        }
 
-        // ---- fast path: can any of my 16 candidates beat the current k-th best? ----
-        float mx = acc[0];
+            if (ch == NCH - 1) {
+                // acc[r] = <query j, target row (r&3) + 8*(r>>2) + 4*h of this tile>
+                if (any_qz) {  // an all-zero query: distance 0 to all-zero targets, 1 to the rest
+                    const unsigned zm = tzbits[(t_begin >> 5) + t];  // wave-uniform scalar load
+                    if (qz) {
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-        const bool hot = dist_from_sim(mx) < tau;
+                        for (int r = 0; r < 16; ++r)
+                            acc[r] = ((zm >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1u) ? 1.0f : 0.0f;
+                    }
+                }
 
-        if (__any(hot)) {
-            // regroup so that lane-half h holds tile rows 16h .. 16h+15 in ascending order
-            float v[16];
+                // ---- fast path: can any of my 16 candidates beat the current k-th best? ----
+                float mx = acc[0];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float lo = acc[r], hi = acc[r + 8];
-                const float recv = __shfl_xor(h == 0 ? hi : lo, 32);
-                // position p = 8u + 4w + x  <->  row 16h + p, with r = 4u + x
-                const int u = r >> 2, x = r & 3;
-                v[8 * u + x] = h == 0 ? lo : recv;      // rows 16h + 8u + x
-                v[8 * u + 4 + x] = h == 0 ? recv : hi;  // rows 16h + 8u + 4 + x
-            }
-            const int row0 = t_begin + t * 32 + 16 * h;  // target row of position 0
-            unsigned mask = 0;
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+                const bool hot = dist_from_sim(mx) < tau;
+
+                if (__any(hot)) {
+                    // regroup so that lane-half h holds tile rows 16h .. 16h+15 in ascending order
+                    float v[16];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const bool ok = (dist_from_sim(v[p]) < tau) && (row0 + p < t_end);
-                mask |= ok ? (1u << p) : 0u;
-            }
+                    for (int r = 0; r < 8; ++r) {
+                        const float lo = acc[r], hi = acc[r + 8];
+                        const float recv = __shfl_xor(h == 0 ? hi : lo, 32);
+                        // position p = 8u + 4w + x  <->  row 16h + p, with r = 4u + x
+                        const int u = r >> 2, x = r & 3;
+                        v[8 * u + x] = h == 0 ? lo : recv;      // rows 16h + 8u + x
+                        v[8 * u + 4 + x] = h == 0 ? recv : hi;  // rows 16h + 8u + 4 + x
+                    }
+                    const int row0 = t_begin + t * 32 + 16 * h;  // target row of position 0
+                    unsigned mask = 0;
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        const bool ok = (dist_from_sim(v[p]) < tau) && (row0 + p < t_end);
+                        mask |= ok ? (1u << p) : 0u;
+                    }
 #pragma unroll 1
-            for (int phase = 0; phase < 2; ++phase) {
-                unsigned m = (h == phase) ? mask : 0u;
-                while (__any(m != 0u)) {
-                    if (m != 0u) {
-                        const int p = __ffs(m) - 1;
-                        m &= m - 1u;
-                        float c = v[0];
+                    for (int phase = 0; phase < 2; ++phase) {
+                        unsigned m = (h == phase) ? mask : 0u;
+                        while (__any(m != 0u)) {
+                            if (m != 0u) {
+                                const int p = __ffs(m) - 1;
+                                m &= m - 1u;
+                                float c = v[0];
 #pragma unroll
-                        for (int i = 1; i < 16; ++i) c = (p == i) ? v[i] : c;
-                        const float dist = dist_from_sim(c);
-                        if (dist < tau) {
-                            const u64 key = ((u64)__float_as_uint(dist) << 32) |
-                                            (unsigned)(t_base + row0 + p);
-                            lists[taupos * 256 + ql] = key;
-                            u64 best = 0;
-                            int bp = 0;
+                                for (int i = 1; i < 16; ++i) c = (p == i) ? v[i] : c;
+                                const float dist = dist_from_sim(c);
+                                if (dist < tau) {
+                                    const u64 key = ((u64)__float_as_uint(dist) << 32) |
+                                                    (unsigned)(t_base + row0 + p);
+                                    lists[taupos * 256 + ql] = key;
+                                    u64 best = 0;
+                                    int bp = 0;
 #pragma unroll 4
-                            for (int e = 0; e < K; ++e) {
-                                const u64 kv = lists[e * 256 + ql];
-                                if (kv > best) {
-                                    best = kv;
-                                    bp = e;
+                                    for (int e = 0; e < K; ++e) {
+                                        const u64 kv = lists[e * 256 + ql];
+                                        if (kv > best) {
+                                            best = kv;
+                                            bp = e;
+                                        }
+                                    }
+                                    taupos = bp;
+                                    tau = __uint_as_float((unsigned)(best >> 32));
                                 }
                             }
-                            taupos = bp;
-                            tau = __uint_as_float((unsigned)(best >> 32));
+                        }
+                        // hand the list's maximum to the other lane of the query
+                        const float tau_o = __shfl_xor(tau, 32);
+                        const int pos_o = __shfl_xor(taupos, 32);
+                        if (h != phase) {
+                            tau = tau_o;
+                            taupos = pos_o;
                         }
                     }
                 }
-                // hand the list's maximum to the other lane of the query
-                const float tau_o = __shfl_xor(tau, 32);
-                const int pos_o = __shfl_xor(taupos, 32);
-                if (h != phase) {
-                    tau = tau_o;
-                    taupos = pos_o;
-                }
             }
-        }
 
-        if (t + 1 < ntiles) store_tile(buf ^ 1);
-        __syncthreads();
+            if (it + 1 < nstages) store_stage(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- write this segment's lists: partial[seg][query][K] ----
@@ -451,10 +468,33 @@ struct fdr_ctx {
     DevBuf ftab, crow, ent;
     // scratch for the host-pointer API
     DevBuf a_indptr, a_indices, E, Ehat, zero, idx, dist, ws;
-    // timing
-    hipEvent_t ev[4][2];
-    bool ev_valid[4] = {false, false, false, false};
+    // timing: when enabled, every launch of kernel kind i gets its own hipEvent pair on the launch
+    // stream; fdr_timing_read() sums the elapsed times of all launches since the last read
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool[FDR_NUM_KERNELS];  // start, stop, start, stop, ...
+    size_t ev_used[FDR_NUM_KERNELS] = {0, 0, 0, 0};
 };
+
+static int timing_begin(fdr_ctx *ctx, int kind, hipStream_t st) {
+    if (!ctx->timing) return FDR_OK;
+    std::vector<hipEvent_t> &pool = ctx->ev_pool[kind];
+    if (ctx->ev_used[kind] + 2 > pool.size()) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        pool.push_back(a);
+        pool.push_back(b);
+    }
+    HIP_TRY(hipEventRecord(pool[ctx->ev_used[kind]], st));
+    return FDR_OK;
+}
+
+static int timing_end(fdr_ctx *ctx, int kind, hipStream_t st) {
+    if (!ctx->timing) return FDR_OK;
+    HIP_TRY(hipEventRecord(ctx->ev_pool[kind][ctx->ev_used[kind] + 1], st));
+    ctx->ev_used[kind] += 2;
+    return FDR_OK;
+}
 
 static int use_device(fdr_ctx *ctx) {
     if (!ctx) return fail(FDR_E_ARG, "null context");
@@ -486,8 +526,6 @@ FDR_EXPORT int fdr_create(int device_id, fdr_ctx **out) {
     HIP_TRY(hipGetDeviceProperties(&c->prop, device_id));
     c->num_cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 4; ++i)
-        for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreate(&c->ev[i][k]));
     *out = c;
     return FDR_OK;
 }
@@ -499,8 +537,8 @@ FDR_EXPORT int fdr_destroy(fdr_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->ftab, &ctx->crow, &ctx->ent, &ctx->a_indptr, &ctx->a_indices, &ctx->E,
                       &ctx->Ehat, &ctx->zero, &ctx->idx, &ctx->dist, &ctx->ws};
     for (DevBuf *b : bufs) b->release();
-    for (int i = 0; i < 4; ++i)
-        for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ctx->ev[i][k]);
+    for (int i = 0; i < FDR_NUM_KERNELS; ++i)
+        for (hipEvent_t e : ctx->ev_pool[i]) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return FDR_OK;
@@ -513,11 +551,29 @@ FDR_EXPORT int fdr_device_info(fdr_ctx *ctx, char *buf, int buflen) {
     return FDR_OK;
 }
 
-FDR_EXPORT int fdr_last_kernel_ms(fdr_ctx *ctx, int which, float *ms_out) {
-    if (!ctx || !ms_out || which < 0 || which > 3) return fail(FDR_E_ARG, "bad argument");
-    if (!ctx->ev_valid[which]) return fail(FDR_E_STATE, "kernel %d has not been launched", which);
-    HIP_TRY(hipEventSynchronize(ctx->ev[which][1]));
-    HIP_TRY(hipEventElapsedTime(ms_out, ctx->ev[which][0], ctx->ev[which][1]));
+FDR_EXPORT int fdr_timing(fdr_ctx *ctx, int enable) {
+    if (!ctx) return fail(FDR_E_ARG, "null context");
+    ctx->timing = enable != 0;
+    for (int i = 0; i < FDR_NUM_KERNELS; ++i) ctx->ev_used[i] = 0;
+    return FDR_OK;
+}
+
+FDR_EXPORT int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (which < 0 || which >= FDR_NUM_KERNELS || !count_out || !total_ms_out)
+        return fail(FDR_E_ARG, "fdr_timing_read: bad argument");
+    float total = 0.f;
+    const size_t used = ctx->ev_used[which];
+    for (size_t i = 0; i + 1 < used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(ctx->ev_pool[which][i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_pool[which][i], ctx->ev_pool[which][i + 1]));
+        total += ms;
+    }
+    *count_out = (int)(used / 2);
+    *total_ms_out = total;
+    ctx->ev_used[which] = 0;
     return FDR_OK;
 }
 
@@ -588,7 +644,8 @@ static int launch_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *d_indptr,
     const int dp = fdr_padded_dim(ctx->d);
     const long long blocks_needed = (n_rows + 3) / 4;
     const int grid = (int)std::min<long long>(blocks_needed, (long long)ctx->num_cus * 8 * 4);
-    HIP_TRY(hipEventRecord(ctx->ev[0][0], st));
+    int trc = timing_begin(ctx, FDR_KERNEL_EMBED, st);
+    if (trc) return trc;
     if (dp == 128)
         hipLaunchKernelGGL(embed_csr_kernel<128>, dim3(grid), dim3(256), 0, st, (long long)n_rows,
                            (const long long *)d_indptr, d_indices, ctx->n_features,
@@ -600,9 +657,7 @@ static int launch_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *d_indptr,
                            (const uint2 *)ctx->ftab.p, (const int *)ctx->crow.p,
                            (const uint2 *)ctx->ent.p, ctx->d, d_E);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev[0][1], st));
-    ctx->ev_valid[0] = true;
-    return FDR_OK;
+    return timing_end(ctx, FDR_KERNEL_EMBED, st);
 }
 
 static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int d, float *d_Ehat,
@@ -614,7 +669,8 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
     const int rb = dp == 128 ? 64 : 32;
     const long long grid = (n_rows + rb - 1) / rb;
     if (grid > 0x7fffffffll) return fail(FDR_E_ARG, "normalize: too many rows");
-    HIP_TRY(hipEventRecord(ctx->ev[1][0], st));
+    int trc = timing_begin(ctx, FDR_KERNEL_NORMALIZE, st);
+    if (trc) return trc;
     if (dp == 128)
         hipLaunchKernelGGL((normalize_rows_kernel<128, 64>), dim3((unsigned)grid), dim3(64), 0, st,
                            d_E, (long long)n_rows, d, d_Ehat, d_zero);
@@ -622,14 +678,14 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
         hipLaunchKernelGGL((normalize_rows_kernel<256, 32>), dim3((unsigned)grid), dim3(64), 0, st,
                            d_E, (long long)n_rows, d, d_Ehat, d_zero);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev[1][1], st));
-    ctx->ev_valid[1] = true;
-    return FDR_OK;
+    return timing_end(ctx, FDR_KERNEL_NORMALIZE, st);
 }
 
 struct KnnPlan {
     int nqb, nseg, seg_len, nq_pad;
-    size_t partial_bytes;
+    size_t bits_bytes;     // packed zero-target flags, at the start of the workspace
+    size_t partial_bytes;  // per-segment top-k lists
+    size_t total_bytes;
 };
 
 static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int k) {
@@ -647,6 +703,8 @@ static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int k) {
     p.nseg = (int)nseg;
     p.seg_len = (int)seg_len;
     p.partial_bytes = (size_t)p.nseg * p.nq_pad * (size_t)k * sizeof(u64);
+    p.bits_bytes = ((size_t)((nt + 31) / 32) * 4 + 255) / 256 * 256;
+    p.total_bytes = p.bits_bytes + p.partial_bytes;
     return p;
 }
 
@@ -654,7 +712,7 @@ FDR_EXPORT size_t fdr_knn_workspace_bytes(fdr_ctx *ctx, int64_t nq, int64_t nt, 
                                           int32_t k) {
     (void)d;
     if (!ctx || nq <= 0 || nt <= 0 || k <= 0) return 0;
-    return knn_plan(ctx, nq, nt, k).partial_bytes;
+    return knn_plan(ctx, nq, nt, k).total_bytes;
 }
 
 static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
@@ -671,33 +729,36 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     if (!d_Qhat || !d_qzero || !d_That || !d_tzero || !d_idx || !d_dist || !d_ws)
         return fail(FDR_E_ARG, "knn: null device pointer");
     const KnnPlan p = knn_plan(ctx, nq, nt, k);
-    if (ws_bytes < p.partial_bytes)
-        return fail(FDR_E_ARG, "knn: workspace %zu < required %zu bytes", ws_bytes, p.partial_bytes);
-    const size_t lds = (size_t)2 * 32 * dp * 4 + (size_t)k * 256 * 8 + 64;
+    if (ws_bytes < p.total_bytes)
+        return fail(FDR_E_ARG, "knn: workspace %zu < required %zu bytes", ws_bytes, p.total_bytes);
+    unsigned *d_bits = reinterpret_cast<unsigned *>(d_ws);
+    u64 *d_partial = reinterpret_cast<u64 *>(static_cast<char *>(d_ws) + p.bits_bytes);
+    hipLaunchKernelGGL(pack_zero_bits_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st,
+                       d_tzero, (int)nt, d_bits);
+    HIP_TRY(hipGetLastError());
+    const size_t lds = (size_t)2 * 32 * 128 * 4 + (size_t)k * 256 * 8;
     if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn: k=%d, d=%d needs %zu B of LDS (> 160 KiB)", k, d, lds);
     dim3 grid((unsigned)p.nqb, (unsigned)p.nseg);
-    HIP_TRY(hipEventRecord(ctx->ev[2][0], st));
+    int trc = timing_begin(ctx, FDR_KERNEL_KNN_TILE, st);
+    if (trc) return trc;
     if (dp == 128) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<128>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(knn_tile_kernel<128>, grid, dim3(512), lds, st, d_Qhat, d_qzero, (int)nq,
-                           d_That, d_tzero, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, (u64 *)d_ws);
+                           d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial);
     } else {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<256>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(knn_tile_kernel<256>, grid, dim3(512), lds, st, d_Qhat, d_qzero, (int)nq,
-                           d_That, d_tzero, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, (u64 *)d_ws);
+                           d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev[2][1], st));
-    ctx->ev_valid[2] = true;
-    HIP_TRY(hipEventRecord(ctx->ev[3][0], st));
+    if ((trc = timing_end(ctx, FDR_KERNEL_KNN_TILE, st))) return trc;
+    if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_MERGE, st))) return trc;
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
-                       (const u64 *)d_ws, p.nseg, (int)nq, p.nq_pad, k, d_idx, d_dist);
+                       (const u64 *)d_partial, p.nseg, (int)nq, p.nq_pad, k, d_idx, d_dist);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev[3][1], st));
-    ctx->ev_valid[3] = true;
-    return FDR_OK;
+    return timing_end(ctx, FDR_KERNEL_KNN_MERGE, st);
 }
 
 // ---- device-pointer API ----------------------------------------------------------------------

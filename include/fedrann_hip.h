@@ -101,10 +101,17 @@ int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64
                 const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int32_t d,
                 int32_t k, int32_t *d_idx, float *d_dist, void *d_workspace, size_t workspace_bytes,
                 void *stream);
-/* Duration in ms of the most recent kernel of each kind launched through this context
- * (hipEvent pair recorded on the launch stream); synchronises on the stop event.
- * which: 0 = embed, 1 = normalize, 2 = knn tile kernel, 3 = knn merge. */
-int fdr_last_kernel_ms(fdr_ctx *ctx, int which, float *ms_out);
+/* ---- per-kernel timing (bench.py's roofline figures) -----------------------------------------
+ * With timing enabled every kernel launch is bracketed by its own hipEvent pair recorded on the
+ * stream the kernel is launched on.  fdr_timing_read() waits for the recorded launches of one kernel
+ * kind, returns how many there were and their summed duration, and clears the tally. */
+#define FDR_KERNEL_EMBED 0
+#define FDR_KERNEL_NORMALIZE 1
+#define FDR_KERNEL_KNN_TILE 2
+#define FDR_KERNEL_KNN_MERGE 3
+#define FDR_NUM_KERNELS 4
+int fdr_timing(fdr_ctx *ctx, int enable);
+int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out);
 
 #ifdef __cplusplus
 }
