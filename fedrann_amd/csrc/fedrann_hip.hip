@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -201,12 +202,92 @@ __global__ __launch_bounds__(256) void pack_zero_bits_kernel(const unsigned char
     if (lane == 32 && i < n) bits[i >> 5] = (unsigned)(m >> 32);
 }
 
-template <int DP>
-__global__ __launch_bounds__(512, (DP <= 128 ? 4 : 2)) void knn_tile_kernel(
+// Top-k update for one 32x32 accumulator tile (one query per lane pair).  acc[r] = similarity of
+// query j with tile row (r&3) + 8*(r>>2) + 4*h.  lists: K x 256 keys, column ql is this query's.
+__device__ __forceinline__ void topk_update(f32x16 acc, const bool qz, const bool any_qz,
+                                            const unsigned zmask, float &tau, int &taupos,
+                                            u64 *__restrict__ lists, const int ql, const int K,
+                                            const int h, const int tile_row0, const int t_end,
+                                            const int t_base) {
+    if (any_qz) {  // an all-zero query: distance 0 to all-zero targets, 1 to every other row
+        if (qz) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[r] = ((zmask >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1u) ? 1.0f : 0.0f;
+        }
+    }
+    // ---- fast path: can any of my 16 candidates beat the current k-th best? ----
+    float mx = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+    const bool hot = dist_from_sim(mx) < tau;
+    if (!__any(hot)) return;
+
+    // ---- slow path: regroup so that lane-half h holds tile rows 16h .. 16h+15 in ascending order
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float lo = acc[r], hi = acc[r + 8];
+        const float recv = __shfl_xor(h == 0 ? hi : lo, 32);
+        const int u = r >> 2, x = r & 3;        // position p = 8u + 4w + x  <->  row 16h + p
+        v[8 * u + x] = h == 0 ? lo : recv;      // rows 16h + 8u + x
+        v[8 * u + 4 + x] = h == 0 ? recv : hi;  // rows 16h + 8u + 4 + x
+    }
+    const int row0 = tile_row0 + 16 * h;  // target row of position 0
+    unsigned mask = 0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const bool ok = (dist_from_sim(v[p]) < tau) && (row0 + p < t_end);
+        mask |= ok ? (1u << p) : 0u;
+    }
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+        unsigned m = (h == phase) ? mask : 0u;
+        while (__any(m != 0u)) {
+            if (m != 0u) {
+                const int p = __ffs(m) - 1;
+                m &= m - 1u;
+                float c = v[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) c = (p == i) ? v[i] : c;
+                const float dist = dist_from_sim(c);
+                if (dist < tau) {
+                    const u64 key = ((u64)__float_as_uint(dist) << 32) | (unsigned)(t_base + row0 + p);
+                    lists[taupos * 256 + ql] = key;
+                    u64 best = 0;
+                    int bp = 0;
+#pragma unroll 4
+                    for (int e = 0; e < K; ++e) {
+                        const u64 kv = lists[e * 256 + ql];
+                        if (kv > best) {
+                            best = kv;
+                            bp = e;
+                        }
+                    }
+                    taupos = bp;
+                    tau = __uint_as_float((unsigned)(best >> 32));
+                }
+            }
+        }
+        // hand the list's maximum to the other lane of the query
+        const float tau_o = __shfl_xor(tau, 32);
+        const int pos_o = __shfl_xor(taupos, 32);
+        if (h != phase) {
+            tau = tau_o;
+            taupos = pos_o;
+        }
+    }
+}
+
+// DP: padded embedding length.  NQ: 32-query sets per wave (independent MFMA accumulator chains
+// that share every A fragment).  A workgroup always owns 256 queries = 8 / NQ waves.
+template <int DP, int NQ>
+__global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
     const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
     const float *__restrict__ Th, const unsigned *__restrict__ tzbits, int nt, int t_base,
-    int seg_len, int K, int nq_pad, u64 *__restrict__ partial) {
+    int seg_len, int K, int nq_pad, u64 *__restrict__ partial, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = 512 / NQ;             // threads per workgroup
     constexpr int NCH = DP / 128;            // 128-component K-chunks per tile
     constexpr int STAGE_FLOATS = 32 * 128;   // one stage = 32 target rows x 128 components (16 KB)
     constexpr int SLOTS = 32;                // 16-byte slots per staged row
@@ -216,169 +297,117 @@ __global__ __launch_bounds__(512, (DP <= 128 ? 4 : 2)) void knn_tile_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int ql = wave * 32 + j;
-    const int qg = blockIdx.x * 256 + ql;
-    const int qrow = qg < nq ? qg : nq - 1;
-    const bool qz = qzero[qrow] != 0;
-    const bool any_qz = __any(qz);
 
-    // queries: this lane's B fragments for all DP/2 K-steps
-    float b[DP / 2];
-    {
+    // queries: this lane's B fragments for all DP/2 K-steps of each of its NQ query sets
+    float b[NQ][DP / 2];
+    bool qz[NQ];
+    int ql[NQ];
+    bool any_qz = false;
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) {
+        ql[s] = (wave * NQ + s) * 32 + j;
+        const int qg = blockIdx.x * 256 + ql[s];
+        const int qrow = qg < nq ? qg : nq - 1;
+        qz[s] = qzero[qrow] != 0;
+        any_qz = any_qz || __any(qz[s]);
         const f32x4 *qp = reinterpret_cast<const f32x4 *>(Qh + (size_t)qrow * DP);
 #pragma unroll
         for (int g = 0; g < DP / 8; ++g) {
             const f32x4 v = qp[2 * g + h];
-            b[4 * g + 0] = v.x;
-            b[4 * g + 1] = v.y;
-            b[4 * g + 2] = v.z;
-            b[4 * g + 3] = v.w;
+            b[s][4 * g + 0] = v.x;
+            b[s][4 * g + 1] = v.y;
+            b[s][4 * g + 2] = v.z;
+            b[s][4 * g + 3] = v.w;
         }
     }
-    for (int i = tid; i < K * 256; i += 512) lists[i] = KEY_INF;
-    float tau = __builtin_inff();
-    int taupos = 0;
+    for (int i = tid; i < K * 256; i += NT) lists[i] = KEY_INF;
+    float tau[NQ];
+    int taupos[NQ];
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) {
+        tau[s] = __builtin_inff();
+        taupos[s] = 0;
+    }
 
     const int t_begin = blockIdx.y * seg_len;  // multiple of 32
     const int t_end = min(nt, t_begin + seg_len);
     const int ntiles = (t_end - t_begin + 31) >> 5;
     const int nstages = ntiles * NCH;
 
-    // staging: 16 KB per stage = two 16-byte loads per thread; rows are XOR-swizzled by slot so
-    // that the MFMA loop's ds_read_b128 (32 rows x one slot) is bank-conflict free
-    f32x4 stage[2];
-    auto load_stage = [&](int it) {
+    // staging by LDS-DMA (global_load_lds_dwordx4): each wave-instruction fills 1 KiB = two staged
+    // rows, linearly; the XOR swizzle that makes the MFMA loop's ds_read_b128 (32 rows x one slot)
+    // bank-conflict free is applied to the SOURCE slot instead.  Rows past the segment end re-read
+    // the last valid row (finite garbage; such candidates are masked by the t_end test).
+    constexpr int PPW = 16 / (NT / 64);  // 1 KiB pieces per wave per stage
+    auto issue_stage = [&](int it, int buf) {
         const int t = it / NCH, ch = it % NCH;
         const int trow0 = t_begin + t * 32;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int f4 = tid + 512 * u;
-            const int row = f4 >> 5, slot = f4 & 31;
-            const int trow = trow0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (trow < t_end)
-                v = reinterpret_cast<const f32x4 *>(Th + (size_t)trow * DP)[ch * SLOTS + slot];
-            stage[u] = v;
-        }
-    };
-    auto store_stage = [&](int buf) {
-        f32x4 *sb = reinterpret_cast<f32x4 *>(stages + buf * STAGE_FLOATS);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int f4 = tid + 512 * u;
-            const int row = f4 >> 5, slot = f4 & 31;
-            sb[row * SLOTS + (slot ^ (row & 15))] = stage[u];
+        for (int u = 0; u < PPW; ++u) {
+            const int piece = wave * PPW + u;
+            const int row = 2 * piece + h, pslot = j;  // lane L writes bytes [16L, 16L+16) of the piece
+            const int trow = min(trow0 + row, t_end - 1);
+            const float *src = Th + (size_t)trow * DP + (size_t)(ch * SLOTS + (pslot ^ (row & 15))) * 4;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)src,
+                (__attribute__((address_space(3))) void *)(smem + buf * (STAGE_FLOATS * 4) + piece * 1024),
+                16, 0, 0);
         }
     };
 
-    if (nstages > 0) {
-        load_stage(0);
-        store_stage(0);
-    }
+    if (nstages > 0) issue_stage(0, 0);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc[NQ];
+#pragma unroll
+        for (int s = 0; s < NQ; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int it = t * NCH + ch;
             const int buf = it & 1;
-            if (it + 1 < nstages) load_stage(it + 1);
+            if (it + 1 < nstages) issue_stage(it + 1, buf ^ 1);  // lands before the barrier below
 
-            // ---- 32 targets x 32 queries x 128 components: 64 chained MFMAs ----
+            // ---- 32 targets x (NQ x 32) queries x 128 components ----
             {
                 const f32x4 *sb = reinterpret_cast<const f32x4 *>(stages + buf * STAGE_FLOATS) + j * SLOTS;
                 const int sw = j & 15;
+                f32x4 a[3];  // fragment ring: two groups prefetched ahead of the MFMAs
+                a[0] = sb[(0 + h) ^ sw];
+                a[1] = sb[(2 + h) ^ sw];
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
-                    const f32x4 a = sb[(2 * g + h) ^ sw];
+                    if (g + 2 < 16) a[(g + 2) % 3] = sb[(2 * (g + 2) + h) ^ sw];
+                    const f32x4 av = a[g % 3];
                     const int bb = 64 * ch + 4 * g;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[bb + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[bb + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[bb + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[bb + 3], acc, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int s = 0; s < NQ; ++s)
+                            acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], b[s][bb + e], acc[s], 0, 0, 0);
                 }
             }
 
             if (ch == NCH - 1) {
-                // acc[r] = <query j, target row (r&3) + 8*(r>>2) + 4*h of this tile>
-                if (any_qz) {  // an all-zero query: distance 0 to all-zero targets, 1 to the rest
-                    const unsigned zm = tzbits[(t_begin >> 5) + t];  // wave-uniform scalar load
-                    if (qz) {
+                unsigned zmask = 0;
+                if (any_qz) zmask = tzbits[(t_begin >> 5) + t];  // wave-uniform scalar load
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            acc[r] = ((zm >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1u) ? 1.0f : 0.0f;
+                for (int s = 0; s < NQ; ++s) {
+                    if (dbg & 1) {  // timing experiment: MFMA + fast path only
+                        float mx = acc[s][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[s][r]);
+                        if (mx > 3.0e38f) tau[s] = mx;
+                        continue;
                     }
-                }
-
-                // ---- fast path: can any of my 16 candidates beat the current k-th best? ----
-                float mx = acc[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-                const bool hot = dist_from_sim(mx) < tau;
-
-                if (__any(hot)) {
-                    // regroup so that lane-half h holds tile rows 16h .. 16h+15 in ascending order
-                    float v[16];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const float lo = acc[r], hi = acc[r + 8];
-                        const float recv = __shfl_xor(h == 0 ? hi : lo, 32);
-                        // position p = 8u + 4w + x  <->  row 16h + p, with r = 4u + x
-                        const int u = r >> 2, x = r & 3;
-                        v[8 * u + x] = h == 0 ? lo : recv;      // rows 16h + 8u + x
-                        v[8 * u + 4 + x] = h == 0 ? recv : hi;  // rows 16h + 8u + 4 + x
-                    }
-                    const int row0 = t_begin + t * 32 + 16 * h;  // target row of position 0
-                    unsigned mask = 0;
-#pragma unroll
-                    for (int p = 0; p < 16; ++p) {
-                        const bool ok = (dist_from_sim(v[p]) < tau) && (row0 + p < t_end);
-                        mask |= ok ? (1u << p) : 0u;
-                    }
-#pragma unroll 1
-                    for (int phase = 0; phase < 2; ++phase) {
-                        unsigned m = (h == phase) ? mask : 0u;
-                        while (__any(m != 0u)) {
-                            if (m != 0u) {
-                                const int p = __ffs(m) - 1;
-                                m &= m - 1u;
-                                float c = v[0];
-#pragma unroll
-                                for (int i = 1; i < 16; ++i) c = (p == i) ? v[i] : c;
-                                const float dist = dist_from_sim(c);
-                                if (dist < tau) {
-                                    const u64 key = ((u64)__float_as_uint(dist) << 32) |
-                                                    (unsigned)(t_base + row0 + p);
-                                    lists[taupos * 256 + ql] = key;
-                                    u64 best = 0;
-                                    int bp = 0;
-#pragma unroll 4
-                                    for (int e = 0; e < K; ++e) {
-                                        const u64 kv = lists[e * 256 + ql];
-                                        if (kv > best) {
-                                            best = kv;
-                                            bp = e;
-                                        }
-                                    }
-                                    taupos = bp;
-                                    tau = __uint_as_float((unsigned)(best >> 32));
-                                }
-                            }
-                        }
-                        // hand the list's maximum to the other lane of the query
-                        const float tau_o = __shfl_xor(tau, 32);
-                        const int pos_o = __shfl_xor(taupos, 32);
-                        if (h != phase) {
-                            tau = tau_o;
-                            taupos = pos_o;
-                        }
-                    }
+                    topk_update(acc[s], qz[s], any_qz, zmask, tau[s], taupos[s], lists, ql[s], K, h,
+                                t_begin + t * 32, t_end, t_base);
                 }
             }
 
-            if (it + 1 < nstages) store_stage(buf ^ 1);
-            __syncthreads();
+            __syncthreads();  // (hipcc drains vmcnt before the barrier: the next stage is in LDS)
         }
     }
 
@@ -387,7 +416,7 @@ __global__ __launch_bounds__(512, (DP <= 128 ? 4 : 2)) void knn_tile_kernel(
     {
         u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * 256) * K;
         const int total = 256 * K;
-        for (int i = tid; i < total; i += 512) {
+        for (int i = tid; i < total; i += NT) {
             const int q = i / K, e = i % K;
             out[i] = lists[e * 256 + q];
         }
@@ -697,6 +726,7 @@ static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int k) {
     long long nseg = (want + p.nqb - 1) / std::max(p.nqb, 1);
     const long long max_seg = std::max<long long>(1, nt / 2048);
     nseg = std::max<long long>(1, std::min<long long>(std::min<long long>(nseg, max_seg), 64));
+    if (const char *e = getenv("FDR_KNN_NSEG")) nseg = std::max(1, atoi(e));  // development knob
     long long seg_len = (nt + nseg - 1) / nseg;
     seg_len = (seg_len + 31) / 32 * 32;
     nseg = (nt + seg_len - 1) / seg_len;
@@ -739,18 +769,20 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     const size_t lds = (size_t)2 * 32 * 128 * 4 + (size_t)k * 256 * 8;
     if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn: k=%d, d=%d needs %zu B of LDS (> 160 KiB)", k, d, lds);
     dim3 grid((unsigned)p.nqb, (unsigned)p.nseg);
+    const char *dbg_env = getenv("FDR_KNN_DEBUG");  // development knob, see DESIGN.md
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
     int trc = timing_begin(ctx, FDR_KERNEL_KNN_TILE, st);
     if (trc) return trc;
     if (dp == 128) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<128>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<128, 2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(knn_tile_kernel<128>, grid, dim3(512), lds, st, d_Qhat, d_qzero, (int)nq,
-                           d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial);
+        hipLaunchKernelGGL((knn_tile_kernel<128, 2>), grid, dim3(256), lds, st, d_Qhat, d_qzero, (int)nq,
+                           d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial, dbg);
     } else {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<256>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<256, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(knn_tile_kernel<256>, grid, dim3(512), lds, st, d_Qhat, d_qzero, (int)nq,
-                           d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial);
+        hipLaunchKernelGGL((knn_tile_kernel<256, 1>), grid, dim3(512), lds, st, d_Qhat, d_qzero, (int)nq,
+                           d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial, dbg);
     }
     HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_TILE, st))) return trc;
