@@ -202,13 +202,78 @@ __global__ __launch_bounds__(256) void pack_zero_bits_kernel(const unsigned char
     if (lane == 32 && i < n) bits[i >> 5] = (unsigned)(m >> 32);
 }
 
-// Top-k update for one 32x32 accumulator tile (one query per lane pair).  acc[r] = similarity of
-// query j with tile row (r&3) + 8*(r>>2) + 4*h.  lists: K x 256 keys, column ql is this query's.
+// ---- top-k state of one 32-query set of a wave ---------------------------------------------------
+// A query (lane pair j / j+32) owns one unsorted list of K keys in LDS (column `ql` of lists[K][256]);
+// taukey / taupos = its current maximum, identical in both lanes.  Each LANE additionally owns a
+// 4-entry append queue in LDS.  Per tile, candidates that beat tau (which may be stale, i.e. too
+// large, between flushes -- that only admits extra candidates) are appended to the lane's queue with
+// predicated stores; when a queue overflows, and at the end of the segment, the whole wave flushes:
+// every queued key that is still smaller than the list maximum replaces it and the two lanes of the
+// query rescan the list together.  Exactness: keys order by (dist, idx); a rejected candidate has
+// dist >= tau.dist and a larger index than every listed key, so it can never belong to the top-k.
+#define QCAP 4
+
+struct TopkState {
+    u64 taukey;
+    float tau;
+    int taupos;
+    int qcnt;
+};
+
+template <int NT>
+__device__ __forceinline__ void topk_flush(TopkState &st, u64 *__restrict__ lists,
+                                           u64 *__restrict__ queue, const int ql, const int K,
+                                           const int tid, const int h) {
+    const int cnt_me = st.qcnt;
+    const int cnt_other = __shfl_xor(cnt_me, 32);
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        const int owner_cnt = (h == ph) ? cnt_me : cnt_other;
+        const int owner_tid = (tid & ~32) | (ph << 5);
+#pragma unroll 1
+        for (int i = 0; i < QCAP; ++i) {
+            const bool active = i < owner_cnt;
+            if (!__any(active)) break;
+            u64 key = KEY_INF;
+            if (active) key = queue[i * NT + owner_tid];
+            const bool ins = active && key < st.taukey;
+            if (__any(ins)) {
+                if (ins) {
+                    if (h == 0) lists[st.taupos * 256 + ql] = key;
+                    // both lanes of the query rescan the list: lane-half h takes entries h, h+2, ...
+                    u64 best = 0;
+                    int bp = 0;
+                    for (int e = h; e < K; e += 2) {
+                        const u64 kv = lists[e * 256 + ql];
+                        if (kv > best) {
+                            best = kv;
+                            bp = e;
+                        }
+                    }
+                    const u64 ob = __shfl_xor(best, 32);
+                    const int op = __shfl_xor(bp, 32);
+                    if (ob > best) {
+                        best = ob;
+                        bp = op;
+                    }
+                    st.taukey = best;
+                    st.taupos = bp;
+                    st.tau = __uint_as_float((unsigned)(best >> 32));
+                }
+            }
+        }
+    }
+    st.qcnt = 0;
+}
+
+// acc[r] = similarity of query j with tile row (r&3) + 8*(r>>2) + 4*h; nvalid = rows of this tile
+// that exist (>= 32 except in the last tile of a segment).
+template <int NT>
 __device__ __forceinline__ void topk_update(f32x16 acc, const bool qz, const bool any_qz,
-                                            const unsigned zmask, float &tau, int &taupos,
-                                            u64 *__restrict__ lists, const int ql, const int K,
-                                            const int h, const int tile_row0, const int t_end,
-                                            const int t_base) {
+                                            const unsigned zmask, TopkState &st,
+                                            u64 *__restrict__ lists, u64 *__restrict__ queue,
+                                            const int ql, const int K, const int tid, const int h,
+                                            const int idx0, const int nvalid) {
     if (any_qz) {  // an all-zero query: distance 0 to all-zero targets, 1 to every other row
         if (qz) {
 #pragma unroll
@@ -220,67 +285,34 @@ __device__ __forceinline__ void topk_update(f32x16 acc, const bool qz, const boo
     float mx = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-    const bool hot = dist_from_sim(mx) < tau;
-    if (!__any(hot)) return;
+    if (!__any(dist_from_sim(mx) < st.tau)) return;
 
-    // ---- slow path: regroup so that lane-half h holds tile rows 16h .. 16h+15 in ascending order
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const float lo = acc[r], hi = acc[r + 8];
-        const float recv = __shfl_xor(h == 0 ? hi : lo, 32);
-        const int u = r >> 2, x = r & 3;        // position p = 8u + 4w + x  <->  row 16h + p
-        v[8 * u + x] = h == 0 ? lo : recv;      // rows 16h + 8u + x
-        v[8 * u + 4 + x] = h == 0 ? recv : hi;  // rows 16h + 8u + 4 + x
-    }
-    const int row0 = tile_row0 + 16 * h;  // target row of position 0
-    unsigned mask = 0;
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const bool ok = (dist_from_sim(v[p]) < tau) && (row0 + p < t_end);
-        mask |= ok ? (1u << p) : 0u;
-    }
+    unsigned todo = 0xffffu;
 #pragma unroll 1
-    for (int phase = 0; phase < 2; ++phase) {
-        unsigned m = (h == phase) ? mask : 0u;
-        while (__any(m != 0u)) {
-            if (m != 0u) {
-                const int p = __ffs(m) - 1;
-                m &= m - 1u;
-                float c = v[0];
+    while (true) {
+        unsigned ovf = 0;
 #pragma unroll
-                for (int i = 1; i < 16; ++i) c = (p == i) ? v[i] : c;
-                const float dist = dist_from_sim(c);
-                if (dist < tau) {
-                    const u64 key = ((u64)__float_as_uint(dist) << 32) | (unsigned)(t_base + row0 + p);
-                    lists[taupos * 256 + ql] = key;
-                    u64 best = 0;
-                    int bp = 0;
-#pragma unroll 4
-                    for (int e = 0; e < K; ++e) {
-                        const u64 kv = lists[e * 256 + ql];
-                        if (kv > best) {
-                            best = kv;
-                            bp = e;
-                        }
-                    }
-                    taupos = bp;
-                    tau = __uint_as_float((unsigned)(best >> 32));
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float dist = dist_from_sim(acc[r]);
+            if (((todo >> r) & 1u) && dist < st.tau && row < nvalid) {
+                if (st.qcnt < QCAP) {
+                    queue[st.qcnt * NT + tid] = ((u64)__float_as_uint(dist) << 32) | (unsigned)(idx0 + row);
+                    ++st.qcnt;
+                } else {
+                    ovf |= 1u << r;
                 }
             }
         }
-        // hand the list's maximum to the other lane of the query
-        const float tau_o = __shfl_xor(tau, 32);
-        const int pos_o = __shfl_xor(taupos, 32);
-        if (h != phase) {
-            tau = tau_o;
-            taupos = pos_o;
-        }
+        if (!__any(ovf != 0u)) break;
+        topk_flush<NT>(st, lists, queue, ql, K, tid, h);
+        todo = ovf;
     }
 }
 
 // DP: padded embedding length.  NQ: 32-query sets per wave (independent MFMA accumulator chains
 // that share every A fragment).  A workgroup always owns 256 queries = 8 / NQ waves.
+// LDS: 2 stages of 32 target rows x 64 components (16 KB) | lists K x 256 keys | queues.
 template <int DP, int NQ>
 __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
     const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
@@ -288,11 +320,11 @@ __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
     int seg_len, int K, int nq_pad, u64 *__restrict__ partial, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 512 / NQ;             // threads per workgroup
-    constexpr int NCH = DP / 128;            // 128-component K-chunks per tile
-    constexpr int STAGE_FLOATS = 32 * 128;   // one stage = 32 target rows x 128 components (16 KB)
-    constexpr int SLOTS = 32;                // 16-byte slots per staged row
-    float *stages = reinterpret_cast<float *>(smem);                    // 2 stages
-    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_FLOATS * 4);  // K * 256 keys
+    constexpr int NCH = DP / 64;             // 64-component K-chunks per tile
+    constexpr int STAGE_BYTES = 32 * 64 * 4; // one stage = 32 target rows x 64 components (8 KB)
+    constexpr int SLOTS = 16;                // 16-byte slots per staged row
+    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES);                    // K * 256 keys
+    u64 *queues = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES + (size_t)K * 2048);  // NQ*QCAP*NT
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -321,12 +353,13 @@ __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
         }
     }
     for (int i = tid; i < K * 256; i += NT) lists[i] = KEY_INF;
-    float tau[NQ];
-    int taupos[NQ];
+    TopkState st[NQ];
 #pragma unroll
     for (int s = 0; s < NQ; ++s) {
-        tau[s] = __builtin_inff();
-        taupos[s] = 0;
+        st[s].taukey = KEY_INF;
+        st[s].tau = __builtin_inff();
+        st[s].taupos = 0;
+        st[s].qcnt = 0;
     }
 
     const int t_begin = blockIdx.y * seg_len;  // multiple of 32
@@ -334,24 +367,23 @@ __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
     const int ntiles = (t_end - t_begin + 31) >> 5;
     const int nstages = ntiles * NCH;
 
-    // staging by LDS-DMA (global_load_lds_dwordx4): each wave-instruction fills 1 KiB = two staged
-    // rows, linearly; the XOR swizzle that makes the MFMA loop's ds_read_b128 (32 rows x one slot)
-    // bank-conflict free is applied to the SOURCE slot instead.  Rows past the segment end re-read
-    // the last valid row (finite garbage; such candidates are masked by the t_end test).
-    constexpr int PPW = 16 / (NT / 64);  // 1 KiB pieces per wave per stage
+    // staging by LDS-DMA (global_load_lds_dwordx4): each wave-instruction fills 1 KiB = four staged
+    // rows of 256 B, linearly; the XOR swizzle that makes the MFMA loop's ds_read_b128 (32 rows x one
+    // slot) bank-conflict free is applied to the SOURCE slot instead.  Rows past the segment end
+    // re-read the last valid row (finite garbage; such candidates are masked by nvalid).
+    constexpr int PPW = 8 / (NT / 64);  // 1 KiB pieces per wave per stage
     auto issue_stage = [&](int it, int buf) {
         const int t = it / NCH, ch = it % NCH;
         const int trow0 = t_begin + t * 32;
 #pragma unroll
         for (int u = 0; u < PPW; ++u) {
             const int piece = wave * PPW + u;
-            const int row = 2 * piece + h, pslot = j;  // lane L writes bytes [16L, 16L+16) of the piece
+            const int row = 4 * piece + (lane >> 4), pslot = lane & 15;
             const int trow = min(trow0 + row, t_end - 1);
             const float *src = Th + (size_t)trow * DP + (size_t)(ch * SLOTS + (pslot ^ (row & 15))) * 4;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)src,
-                (__attribute__((address_space(3))) void *)(smem + buf * (STAGE_FLOATS * 4) + piece * 1024),
-                16, 0, 0);
+                (__attribute__((address_space(3))) void *)(smem + buf * STAGE_BYTES + piece * 1024), 16, 0, 0);
         }
     };
 
@@ -370,18 +402,18 @@ __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
             const int buf = it & 1;
             if (it + 1 < nstages) issue_stage(it + 1, buf ^ 1);  // lands before the barrier below
 
-            // ---- 32 targets x (NQ x 32) queries x 128 components ----
+            // ---- 32 targets x (NQ x 32) queries x 64 components ----
             {
-                const f32x4 *sb = reinterpret_cast<const f32x4 *>(stages + buf * STAGE_FLOATS) + j * SLOTS;
+                const f32x4 *sb = reinterpret_cast<const f32x4 *>(smem + buf * STAGE_BYTES) + j * SLOTS;
                 const int sw = j & 15;
                 f32x4 a[3];  // fragment ring: two groups prefetched ahead of the MFMAs
                 a[0] = sb[(0 + h) ^ sw];
                 a[1] = sb[(2 + h) ^ sw];
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    if (g + 2 < 16) a[(g + 2) % 3] = sb[(2 * (g + 2) + h) ^ sw];
+                for (int g = 0; g < 8; ++g) {
+                    if (g + 2 < 8) a[(g + 2) % 3] = sb[(2 * (g + 2) + h) ^ sw];
                     const f32x4 av = a[g % 3];
-                    const int bb = 64 * ch + 4 * g;
+                    const int bb = 32 * ch + 4 * g;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -393,25 +425,28 @@ __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
             if (ch == NCH - 1) {
                 unsigned zmask = 0;
                 if (any_qz) zmask = tzbits[(t_begin >> 5) + t];  // wave-uniform scalar load
+                const int tile_row0 = t_begin + t * 32;
 #pragma unroll
                 for (int s = 0; s < NQ; ++s) {
                     if (dbg & 1) {  // timing experiment: MFMA + fast path only
                         float mx = acc[s][0];
 #pragma unroll
                         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[s][r]);
-                        if (mx > 3.0e38f) tau[s] = mx;
+                        if (mx > 3.0e38f) st[s].tau = mx;
                         continue;
                     }
-                    topk_update(acc[s], qz[s], any_qz, zmask, tau[s], taupos[s], lists, ql[s], K, h,
-                                t_begin + t * 32, t_end, t_base);
+                    topk_update<NT>(acc[s], qz[s], any_qz, zmask, st[s], lists, queues + s * QCAP * NT,
+                                    ql[s], K, tid, h, t_base + tile_row0, t_end - tile_row0);
                 }
             }
-
             __syncthreads();  // (hipcc drains vmcnt before the barrier: the next stage is in LDS)
         }
     }
 
-    // ---- write this segment's lists: partial[seg][query][K] ----
+    // ---- drain the queues, then write this segment's lists: partial[seg][query][K] ----
+#pragma unroll
+    for (int s = 0; s < NQ; ++s)
+        if (__any(st[s].qcnt > 0)) topk_flush<NT>(st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h);
     __syncthreads();
     {
         u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * 256) * K;
@@ -766,7 +801,8 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     hipLaunchKernelGGL(pack_zero_bits_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st,
                        d_tzero, (int)nt, d_bits);
     HIP_TRY(hipGetLastError());
-    const size_t lds = (size_t)2 * 32 * 128 * 4 + (size_t)k * 256 * 8;
+    // 2 stages x 8 KB | K x 256 keys | per-lane append queues (QCAP x 512 lanes... x 8 B = 16 KB)
+    const size_t lds = (size_t)2 * 32 * 64 * 4 + (size_t)k * 256 * 8 + (size_t)QCAP * 512 * 8;
     if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn: k=%d, d=%d needs %zu B of LDS (> 160 KiB)", k, d, lds);
     dim3 grid((unsigned)p.nqb, (unsigned)p.nseg);
     const char *dbg_env = getenv("FDR_KNN_DEBUG");  // development knob, see DESIGN.md
