@@ -213,6 +213,9 @@ __global__ __launch_bounds__(256) void pack_zero_bits_kernel(const unsigned char
 // dist >= tau.dist and a larger index than every listed key, so it can never belong to the top-k.
 #define QCAP 4
 
+__device__ unsigned long long g_dbg_counters[8];  // development counters (FDR_KNN_DEBUG & 2)
+#define DBG_COUNT(i) do { if (dbgc && (threadIdx.x & 63) == 0) atomicAdd(&g_dbg_counters[i], 1ull); } while (0)
+
 struct TopkState {
     u64 taukey;
     float tau;
@@ -223,7 +226,8 @@ struct TopkState {
 template <int NT>
 __device__ __forceinline__ void topk_flush(TopkState &st, u64 *__restrict__ lists,
                                            u64 *__restrict__ queue, const int ql, const int K,
-                                           const int tid, const int h) {
+                                           const int tid, const int h, const bool dbgc) {
+    DBG_COUNT(2);
     const int cnt_me = st.qcnt;
     const int cnt_other = __shfl_xor(cnt_me, 32);
 #pragma unroll 1
@@ -237,7 +241,9 @@ __device__ __forceinline__ void topk_flush(TopkState &st, u64 *__restrict__ list
             u64 key = KEY_INF;
             if (active) key = queue[i * NT + owner_tid];
             const bool ins = active && key < st.taukey;
+            DBG_COUNT(3);
             if (__any(ins)) {
+                DBG_COUNT(4);
                 if (ins) {
                     if (h == 0) lists[st.taupos * 256 + ql] = key;
                     // both lanes of the query rescan the list: lane-half h takes entries h, h+2, ...
@@ -273,7 +279,8 @@ __device__ __forceinline__ void topk_update(f32x16 acc, const bool qz, const boo
                                             const unsigned zmask, TopkState &st,
                                             u64 *__restrict__ lists, u64 *__restrict__ queue,
                                             const int ql, const int K, const int tid, const int h,
-                                            const int idx0, const int nvalid) {
+                                            const int idx0, const int nvalid, const bool dbgc) {
+    DBG_COUNT(0);
     if (any_qz) {  // an all-zero query: distance 0 to all-zero targets, 1 to every other row
         if (qz) {
 #pragma unroll
@@ -290,6 +297,7 @@ __device__ __forceinline__ void topk_update(f32x16 acc, const bool qz, const boo
     unsigned todo = 0xffffu;
 #pragma unroll 1
     while (true) {
+        DBG_COUNT(1);
         unsigned ovf = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -305,7 +313,7 @@ __device__ __forceinline__ void topk_update(f32x16 acc, const bool qz, const boo
             }
         }
         if (!__any(ovf != 0u)) break;
-        topk_flush<NT>(st, lists, queue, ql, K, tid, h);
+        topk_flush<NT>(st, lists, queue, ql, K, tid, h, dbgc);
         todo = ovf;
     }
 }
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
                         continue;
                     }
                     topk_update<NT>(acc[s], qz[s], any_qz, zmask, st[s], lists, queues + s * QCAP * NT,
-                                    ql[s], K, tid, h, t_base + tile_row0, t_end - tile_row0);
+                                    ql[s], K, tid, h, t_base + tile_row0, t_end - tile_row0, (dbg & 2) != 0);
                 }
             }
             __syncthreads();  // (hipcc drains vmcnt before the barrier: the next stage is in LDS)
@@ -446,7 +454,8 @@ __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
     // ---- drain the queues, then write this segment's lists: partial[seg][query][K] ----
 #pragma unroll
     for (int s = 0; s < NQ; ++s)
-        if (__any(st[s].qcnt > 0)) topk_flush<NT>(st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h);
+        if (__any(st[s].qcnt > 0))
+            topk_flush<NT>(st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h, (dbg & 2) != 0);
     __syncthreads();
     {
         u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * 256) * K;
@@ -821,6 +830,15 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
                            d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial, dbg);
     }
     HIP_TRY(hipGetLastError());
+    if (dbg & 2) {
+        unsigned long long c[8];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_dbg_counters), sizeof(c)));
+        fprintf(stderr, "[fdr debug] grid %d x %d  calls(with tile) %llu  hot-episodes... update_calls=%llu rounds=%llu flushes=%llu flush_iters=%llu rescans=%llu\n",
+                p.nqb, p.nseg, c[0], c[0], c[1], c[2], c[3], c[4]);
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_counters), z, sizeof(z)));
+    }
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_TILE, st))) return trc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_MERGE, st))) return trc;
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
