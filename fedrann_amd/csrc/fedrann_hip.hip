@@ -185,10 +185,14 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restr
 #define KEY_INF 0x7F800000FFFFFFFFull
 
 __device__ __forceinline__ float dist_from_sim(float c) {
-    float dv = 1.0f - c;
-    dv = dv < 0.0f ? 0.0f : dv;
-    dv = dv > 1.0f ? 1.0f : dv;
-    return dv;
+    return __builtin_amdgcn_fmed3f(1.0f - c, 0.0f, 1.0f);  // clamp(1 - c, 0, 1): v_sub + v_med3
+}
+
+// Conservative similarity-space form of "dist_from_sim(c) < tau": every c that passes the exact
+// test satisfies c > sim_floor(tau) (both roundings involved are below 6e-8 in [0,1]); candidates
+// above the floor are re-tested exactly before they are queued.
+__device__ __forceinline__ float sim_floor(float tau) {
+    return tau <= 1.0f ? (1.0f - tau) - 3.0e-7f : -__builtin_inff();
 }
 
 // zero-row byte flags -> one bit per target row (bit r of word w = row 32w + r)
@@ -217,16 +221,17 @@ __device__ unsigned long long g_dbg_counters[8];  // development counters (FDR_K
 #define DBG_COUNT(i) do { if (dbgc && (threadIdx.x & 63) == 0) atomicAdd(&g_dbg_counters[i], 1ull); } while (0)
 
 struct TopkState {
-    u64 taukey;
-    float tau;
-    int taupos;
-    int qcnt;
+    u64 taukey;   // maximum key of the query's list (both lanes of the query hold the same value)
+    float tau;    // its distance part
+    float cfloor; // sim_floor(tau)
+    int taupos;   // its position in the list
+    int qcnt;     // entries in this LANE's append queue
 };
 
 template <int NT>
-__device__ __forceinline__ void topk_flush(TopkState &st, u64 *__restrict__ lists,
-                                           u64 *__restrict__ queue, const int ql, const int K,
-                                           const int tid, const int h, const bool dbgc) {
+__device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lists,
+                                             u64 *__restrict__ queue, const int ql, const int K,
+                                             const int tid, const int h, const bool dbgc) {
     DBG_COUNT(2);
     const int cnt_me = st.qcnt;
     const int cnt_other = __shfl_xor(cnt_me, 32);
@@ -249,6 +254,7 @@ __device__ __forceinline__ void topk_flush(TopkState &st, u64 *__restrict__ list
                     // both lanes of the query rescan the list: lane-half h takes entries h, h+2, ...
                     u64 best = 0;
                     int bp = 0;
+#pragma unroll 2
                     for (int e = h; e < K; e += 2) {
                         const u64 kv = lists[e * 256 + ql];
                         if (kv > best) {
@@ -269,51 +275,49 @@ __device__ __forceinline__ void topk_flush(TopkState &st, u64 *__restrict__ list
             }
         }
     }
+    st.cfloor = sim_floor(st.tau);
     st.qcnt = 0;
+    return st;
 }
 
-// acc[r] = similarity of query j with tile row (r&3) + 8*(r>>2) + 4*h; nvalid = rows of this tile
-// that exist (>= 32 except in the last tile of a segment).
+// Queue every candidate of this tile that beats tau.  acc[r] = similarity of query j with tile row
+// (r&3) + 8*(r>>2) + 4*h; rows >= nvalid do not exist (last tile of a segment only).
 template <int NT>
-__device__ __forceinline__ void topk_update(f32x16 acc, const bool qz, const bool any_qz,
-                                            const unsigned zmask, TopkState &st,
-                                            u64 *__restrict__ lists, u64 *__restrict__ queue,
-                                            const int ql, const int K, const int tid, const int h,
-                                            const int idx0, const int nvalid, const bool dbgc) {
-    DBG_COUNT(0);
-    if (any_qz) {  // an all-zero query: distance 0 to all-zero targets, 1 to every other row
-        if (qz) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[r] = ((zmask >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1u) ? 1.0f : 0.0f;
-        }
-    }
-    // ---- fast path: can any of my 16 candidates beat the current k-th best? ----
-    float mx = acc[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-    if (!__any(dist_from_sim(mx) < st.tau)) return;
-
+__device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64 *__restrict__ lists,
+                                            u64 *__restrict__ queue, const int ql, const int K,
+                                            const int tid, const int h, int idx0, int nvalid,
+                                            const bool dbgc) {
+    // this block is cold: keep its address / index arithmetic from being hoisted into the hot loop
+    asm volatile("" : "+s"(idx0), "+s"(nvalid));
     unsigned todo = 0xffffu;
+    if (nvalid < 32) {
+        todo = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            todo |= ((r & 3) + 8 * (r >> 2) + 4 * h < nvalid) ? (1u << r) : 0u;
+    }
+    const int idxh = idx0 + 4 * h;
 #pragma unroll 1
     while (true) {
         DBG_COUNT(1);
         unsigned ovf = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float dist = dist_from_sim(acc[r]);
-            if (((todo >> r) & 1u) && dist < st.tau && row < nvalid) {
-                if (st.qcnt < QCAP) {
-                    queue[st.qcnt * NT + tid] = ((u64)__float_as_uint(dist) << 32) | (unsigned)(idx0 + row);
-                    ++st.qcnt;
-                } else {
-                    ovf |= 1u << r;
+            if (acc[r] > st.cfloor && ((todo >> r) & 1u)) {
+                const float dist = dist_from_sim(acc[r]);
+                if (dist < st.tau) {
+                    if (st.qcnt < QCAP) {
+                        queue[st.qcnt * NT + tid] =
+                            ((u64)__float_as_uint(dist) << 32) | (unsigned)(idxh + (r & 3) + 8 * (r >> 2));
+                        ++st.qcnt;
+                    } else {
+                        ovf |= 1u << r;
+                    }
                 }
             }
         }
         if (!__any(ovf != 0u)) break;
-        topk_flush<NT>(st, lists, queue, ql, K, tid, h, dbgc);
+        st = topk_flush<NT>(st, lists, queue, ql, K, tid, h, dbgc);
         todo = ovf;
     }
 }
@@ -366,6 +370,7 @@ __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
     for (int s = 0; s < NQ; ++s) {
         st[s].taukey = KEY_INF;
         st[s].tau = __builtin_inff();
+        st[s].cfloor = -__builtin_inff();
         st[s].taupos = 0;
         st[s].qcnt = 0;
     }
@@ -431,20 +436,30 @@ __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
             }
 
             if (ch == NCH - 1) {
-                unsigned zmask = 0;
-                if (any_qz) zmask = tzbits[(t_begin >> 5) + t];  // wave-uniform scalar load
                 const int tile_row0 = t_begin + t * 32;
+                if (any_qz) {  // rare: an all-zero query is at distance 0 from all-zero targets, 1 from the rest
+                    const unsigned zm = tzbits[(t_begin >> 5) + t] >> (4 * h);  // wave-uniform load
+#pragma unroll
+                    for (int s = 0; s < NQ; ++s)
+                        if (qz[s]) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                acc[s][r] = (float)((zm >> ((r & 3) + 8 * (r >> 2))) & 1u);
+                        }
+                }
 #pragma unroll
                 for (int s = 0; s < NQ; ++s) {
-                    if (dbg & 1) {  // timing experiment: MFMA + fast path only
-                        float mx = acc[s][0];
+                    // fast path: can any of my 16 candidates beat the current k-th best?
+                    float mx = acc[s][0];
 #pragma unroll
-                        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[s][r]);
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[s][r]);
+                    if (dbg & 1) {  // timing experiment: MFMA + fast path only
                         if (mx > 3.0e38f) st[s].tau = mx;
                         continue;
                     }
-                    topk_update<NT>(acc[s], qz[s], any_qz, zmask, st[s], lists, queues + s * QCAP * NT,
-                                    ql[s], K, tid, h, t_base + tile_row0, t_end - tile_row0, (dbg & 2) != 0);
+                    if (__any(mx > st[s].cfloor))
+                        topk_append<NT>(acc[s], st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h,
+                                        t_base + tile_row0, t_end - tile_row0, (dbg & 2) != 0);
                 }
             }
             __syncthreads();  // (hipcc drains vmcnt before the barrier: the next stage is in LDS)
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
 #pragma unroll
     for (int s = 0; s < NQ; ++s)
         if (__any(st[s].qcnt > 0))
-            topk_flush<NT>(st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h, (dbg & 2) != 0);
+            st[s] = topk_flush<NT>(st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h, (dbg & 2) != 0);
     __syncthreads();
     {
         u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * 256) * K;
