@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -217,8 +218,12 @@ __global__ __launch_bounds__(256) void pack_zero_bits_kernel(const unsigned char
 // dist >= tau.dist and a larger index than every listed key, so it can never belong to the top-k.
 #define QCAP 4
 
-__device__ unsigned long long g_dbg_counters[8];  // development counters (FDR_KNN_DEBUG & 2)
+#ifdef FDR_DEBUG_COUNTERS  // development build only: event counters read back with FDR_KNN_DEBUG=2
+__device__ unsigned long long g_dbg_counters[8];
 #define DBG_COUNT(i) do { if (dbgc && (threadIdx.x & 63) == 0) atomicAdd(&g_dbg_counters[i], 1ull); } while (0)
+#else
+#define DBG_COUNT(i) do { (void)dbgc; } while (0)
+#endif
 
 struct TopkState {
     u64 taukey;   // maximum key of the query's list (both lanes of the query hold the same value)
@@ -254,13 +259,20 @@ __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lis
                     // both lanes of the query rescan the list: lane-half h takes entries h, h+2, ...
                     u64 best = 0;
                     int bp = 0;
-#pragma unroll 2
-                    for (int e = h; e < K; e += 2) {
-                        const u64 kv = lists[e * 256 + ql];
-                        if (kv > best) {
-                            best = kv;
-                            bp = e;
+#pragma unroll 1
+                    for (int e0 = h; e0 < K; e0 += 16) {  // 8 independent LDS reads per batch
+                        u64 kv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = e0 + 2 * u;
+                            kv[u] = e < K ? lists[e * 256 + ql] : 0ull;
                         }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (kv[u] > best) {
+                                best = kv[u];
+                                bp = e0 + 2 * u;
+                            }
                     }
                     const u64 ob = __shfl_xor(best, 32);
                     const int op = __shfl_xor(bp, 32);
@@ -303,7 +315,9 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
         unsigned ovf = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (acc[r] > st.cfloor && ((todo >> r) & 1u)) {
+            const bool above = acc[r] > st.cfloor;
+            if (!__any(above)) continue;  // wave-uniform skip: two instructions per idle register
+            if (above && ((todo >> r) & 1u)) {
                 const float dist = dist_from_sim(acc[r]);
                 if (dist < st.tau) {
                     if (st.qcnt < QCAP) {
@@ -780,12 +794,25 @@ static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int k) {
     KnnPlan p;
     p.nqb = (int)((nq + 255) / 256);
     p.nq_pad = p.nqb * 256;
-    // enough workgroups to fill 2 per CU several times over, segments not shorter than 2048 targets
-    const long long want = (long long)ctx->num_cus * 8;
-    long long nseg = (want + p.nqb - 1) / std::max(p.nqb, 1);
-    const long long max_seg = std::max<long long>(1, nt / 2048);
-    nseg = std::max<long long>(1, std::min<long long>(std::min<long long>(nseg, max_seg), 64));
-    if (const char *e = getenv("FDR_KNN_NSEG")) nseg = std::max(1, atoi(e));  // development knob
+    // Split the targets into nseg segments so that the grid (nqb x nseg workgroups of equal cost)
+    // fills the chip's workgroup slots in whole "rounds": pick the nseg with the best fill
+    // efficiency, charging ~1.5 % per extra segment for the top-k warm-up each segment repeats.
+    const long long slots = (long long)ctx->num_cus * 2;
+    const long long max_seg = std::max<long long>(1, std::min<long long>(nt / 2048, 24));
+    long long nseg = 1;
+    double best_score = -1.0;
+    for (long long c = 1; c <= max_seg; ++c) {
+        const double rounds = (double)p.nqb * c / (double)slots;
+        const double eff = rounds / std::ceil(rounds);
+        const double score = eff - 0.015 * (double)(c - 1);
+        if (score > best_score + 1e-9) {
+            best_score = score;
+            nseg = c;
+        }
+    }
+    if (const char *e = getenv("FDR_KNN_NSEG")) {  // development knob
+        if (atoi(e) > 0) nseg = atoi(e);
+    }
     long long seg_len = (nt + nseg - 1) / nseg;
     seg_len = (seg_len + 31) / 32 * 32;
     nseg = (nt + seg_len - 1) / seg_len;
@@ -845,6 +872,7 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
                            d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial, dbg);
     }
     HIP_TRY(hipGetLastError());
+#ifdef FDR_DEBUG_COUNTERS
     if (dbg & 2) {
         unsigned long long c[8];
         HIP_TRY(hipStreamSynchronize(st));
@@ -854,6 +882,7 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_counters), z, sizeof(z)));
     }
+#endif
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_TILE, st))) return trc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_MERGE, st))) return trc;
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
