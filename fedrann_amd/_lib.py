@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfedrann_hip.so")
+LIB_PATH = os.environ.get("FEDRANN_HIP_LIB") or os.path.join(HERE, "libfedrann_hip.so")  # env: dev A/B builds
 
 # symbols declared in include/fedrann_hip.h (tests check that the library exports every one)
 SYMBOLS = (

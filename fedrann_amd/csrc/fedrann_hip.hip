@@ -260,15 +260,15 @@ __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lis
                     u64 best = 0;
                     int bp = 0;
 #pragma unroll 1
-                    for (int e0 = h; e0 < K; e0 += 16) {  // 8 independent LDS reads per batch
-                        u64 kv[8];
+                    for (int e0 = h; e0 < K; e0 += 8) {  // 4 independent LDS reads per batch
+                        u64 kv[4];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
+                        for (int u = 0; u < 4; ++u) {
                             const int e = e0 + 2 * u;
                             kv[u] = e < K ? lists[e * 256 + ql] : 0ull;
                         }
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
+                        for (int u = 0; u < 4; ++u)
                             if (kv[u] > best) {
                                 best = kv[u];
                                 bp = e0 + 2 * u;
@@ -340,7 +340,7 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
 // that share every A fragment).  A workgroup always owns 256 queries = 8 / NQ waves.
 // LDS: 2 stages of 32 target rows x 64 components (16 KB) | lists K x 256 keys | queues.
 template <int DP, int NQ>
-__global__ __launch_bounds__(512 / NQ, 2) void knn_tile_kernel(
+__global__ __launch_bounds__(512 / NQ, (DP == 128 && NQ == 1) ? 4 : 2) void knn_tile_kernel(
     const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
     const float *__restrict__ Th, const unsigned *__restrict__ tzbits, int nt, int t_base,
     int seg_len, int K, int nq_pad, u64 *__restrict__ partial, int dbg) {
@@ -860,10 +860,17 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
     int trc = timing_begin(ctx, FDR_KERNEL_KNN_TILE, st);
     if (trc) return trc;
-    if (dp == 128) {
+    const char *nq_env = getenv("FDR_KNN_NQ");  // development knob: query sets per wave at d <= 128
+    const int nq_sets = nq_env ? atoi(nq_env) : 1;
+    if (dp == 128 && nq_sets == 2) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<128, 2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((knn_tile_kernel<128, 2>), grid, dim3(256), lds, st, d_Qhat, d_qzero, (int)nq,
+                           d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial, dbg);
+    } else if (dp == 128) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<128, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((knn_tile_kernel<128, 1>), grid, dim3(512), lds, st, d_Qhat, d_qzero, (int)nq,
                            d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial, dbg);
     } else {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<256, 1>),
