@@ -233,7 +233,7 @@ struct TopkState {
     int qcnt;     // entries in this LANE's append queue
 };
 
-template <int NT>
+template <int NT, int QW>
 __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lists,
                                              u64 *__restrict__ queue, const int ql, const int K,
                                              const int tid, const int h, const bool dbgc) {
@@ -255,24 +255,17 @@ __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lis
             if (__any(ins)) {
                 DBG_COUNT(4);
                 if (ins) {
-                    if (h == 0) lists[st.taupos * 256 + ql] = key;
+                    if (h == 0) lists[st.taupos * QW + ql] = key;
                     // both lanes of the query rescan the list: lane-half h takes entries h, h+2, ...
                     u64 best = 0;
                     int bp = 0;
-#pragma unroll 1
-                    for (int e0 = h; e0 < K; e0 += 8) {  // 4 independent LDS reads per batch
-                        u64 kv[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int e = e0 + 2 * u;
-                            kv[u] = e < K ? lists[e * 256 + ql] : 0ull;
+#pragma unroll 2
+                    for (int e = h; e < K; e += 2) {
+                        const u64 kv = lists[e * QW + ql];
+                        if (kv > best) {
+                            best = kv;
+                            bp = e;
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (kv[u] > best) {
-                                best = kv[u];
-                                bp = e0 + 2 * u;
-                            }
                     }
                     const u64 ob = __shfl_xor(best, 32);
                     const int op = __shfl_xor(bp, 32);
@@ -294,7 +287,7 @@ __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lis
 
 // Queue every candidate of this tile that beats tau.  acc[r] = similarity of query j with tile row
 // (r&3) + 8*(r>>2) + 4*h; rows >= nvalid do not exist (last tile of a segment only).
-template <int NT>
+template <int NT, int QW>
 __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64 *__restrict__ lists,
                                             u64 *__restrict__ queue, const int ql, const int K,
                                             const int tid, const int h, int idx0, int nvalid,
@@ -315,9 +308,7 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
         unsigned ovf = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool above = acc[r] > st.cfloor;
-            if (!__any(above)) continue;  // wave-uniform skip: two instructions per idle register
-            if (above && ((todo >> r) & 1u)) {
+            if (acc[r] > st.cfloor && ((todo >> r) & 1u)) {
                 const float dist = dist_from_sim(acc[r]);
                 if (dist < st.tau) {
                     if (st.qcnt < QCAP) {
@@ -331,26 +322,28 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
             }
         }
         if (!__any(ovf != 0u)) break;
-        st = topk_flush<NT>(st, lists, queue, ql, K, tid, h, dbgc);
+        st = topk_flush<NT, QW>(st, lists, queue, ql, K, tid, h, dbgc);
         todo = ovf;
     }
 }
 
 // DP: padded embedding length.  NQ: 32-query sets per wave (independent MFMA accumulator chains
-// that share every A fragment).  A workgroup always owns 256 queries = 8 / NQ waves.
-// LDS: 2 stages of 32 target rows x 64 components (16 KB) | lists K x 256 keys | queues.
-template <int DP, int NQ>
-__global__ __launch_bounds__(512 / NQ, (DP == 128 && NQ == 1) ? 4 : 2) void knn_tile_kernel(
+// that share every A fragment).  NW: waves per workgroup; a workgroup owns QW = 32*NQ*NW queries.
+// WPS: waves per SIMD the register budget is sized for.
+// LDS: 2 stages of 32 target rows x 64 components (16 KB) | lists K x QW keys | queues.
+template <int DP, int NQ, int NW, int WPS>
+__global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
     const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
     const float *__restrict__ Th, const unsigned *__restrict__ tzbits, int nt, int t_base,
     int seg_len, int K, int nq_pad, u64 *__restrict__ partial, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NT = 512 / NQ;             // threads per workgroup
+    constexpr int NT = 64 * NW;              // threads per workgroup
+    constexpr int QW = 32 * NQ * NW;         // queries per workgroup
     constexpr int NCH = DP / 64;             // 64-component K-chunks per tile
     constexpr int STAGE_BYTES = 32 * 64 * 4; // one stage = 32 target rows x 64 components (8 KB)
     constexpr int SLOTS = 16;                // 16-byte slots per staged row
-    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES);                    // K * 256 keys
-    u64 *queues = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES + (size_t)K * 2048);  // NQ*QCAP*NT
+    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES);                         // K * QW keys
+    u64 *queues = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES + (size_t)K * QW * 8);  // NQ*QCAP*NT
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -364,7 +357,7 @@ __global__ __launch_bounds__(512 / NQ, (DP == 128 && NQ == 1) ? 4 : 2) void knn_
 #pragma unroll
     for (int s = 0; s < NQ; ++s) {
         ql[s] = (wave * NQ + s) * 32 + j;
-        const int qg = blockIdx.x * 256 + ql[s];
+        const int qg = blockIdx.x * QW + ql[s];
         const int qrow = qg < nq ? qg : nq - 1;
         qz[s] = qzero[qrow] != 0;
         any_qz = any_qz || __any(qz[s]);
@@ -378,7 +371,7 @@ __global__ __launch_bounds__(512 / NQ, (DP == 128 && NQ == 1) ? 4 : 2) void knn_
             b[s][4 * g + 3] = v.w;
         }
     }
-    for (int i = tid; i < K * 256; i += NT) lists[i] = KEY_INF;
+    for (int i = tid; i < K * QW; i += NT) lists[i] = KEY_INF;
     TopkState st[NQ];
 #pragma unroll
     for (int s = 0; s < NQ; ++s) {
@@ -398,13 +391,14 @@ __global__ __launch_bounds__(512 / NQ, (DP == 128 && NQ == 1) ? 4 : 2) void knn_
     // rows of 256 B, linearly; the XOR swizzle that makes the MFMA loop's ds_read_b128 (32 rows x one
     // slot) bank-conflict free is applied to the SOURCE slot instead.  Rows past the segment end
     // re-read the last valid row (finite garbage; such candidates are masked by nvalid).
-    constexpr int PPW = 8 / (NT / 64);  // 1 KiB pieces per wave per stage
+    constexpr int NPIECE = 8;  // 1 KiB pieces per stage, dealt round-robin to the waves
     auto issue_stage = [&](int it, int buf) {
         const int t = it / NCH, ch = it % NCH;
         const int trow0 = t_begin + t * 32;
 #pragma unroll
-        for (int u = 0; u < PPW; ++u) {
-            const int piece = wave * PPW + u;
+        for (int u = 0; u < (NPIECE + NW - 1) / NW; ++u) {
+            const int piece = wave + NW * u;
+            if (NPIECE % NW != 0 && piece >= NPIECE) break;
             const int row = 4 * piece + (lane >> 4), pslot = lane & 15;
             const int trow = min(trow0 + row, t_end - 1);
             const float *src = Th + (size_t)trow * DP + (size_t)(ch * SLOTS + (pslot ^ (row & 15))) * 4;
@@ -472,7 +466,7 @@ __global__ __launch_bounds__(512 / NQ, (DP == 128 && NQ == 1) ? 4 : 2) void knn_
                         continue;
                     }
                     if (__any(mx > st[s].cfloor))
-                        topk_append<NT>(acc[s], st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h,
+                        topk_append<NT, QW>(acc[s], st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h,
                                         t_base + tile_row0, t_end - tile_row0, (dbg & 2) != 0);
                 }
             }
@@ -484,14 +478,14 @@ __global__ __launch_bounds__(512 / NQ, (DP == 128 && NQ == 1) ? 4 : 2) void knn_
 #pragma unroll
     for (int s = 0; s < NQ; ++s)
         if (__any(st[s].qcnt > 0))
-            st[s] = topk_flush<NT>(st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h, (dbg & 2) != 0);
+            st[s] = topk_flush<NT, QW>(st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h, (dbg & 2) != 0);
     __syncthreads();
     {
-        u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * 256) * K;
-        const int total = 256 * K;
+        u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * QW) * K;
+        const int total = QW * K;
         for (int i = tid; i < total; i += NT) {
             const int q = i / K, e = i % K;
-            out[i] = lists[e * 256 + q];
+            out[i] = lists[e * QW + q];
         }
     }
 }
@@ -783,21 +777,61 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
     return timing_end(ctx, FDR_KERNEL_NORMALIZE, st);
 }
 
+// Kernel shapes.  queries/workgroup QW = 32*NQ*NW; slots = workgroups resident per CU (LDS- and
+// register-limited).  Shape choice: see knn_choose_shape().
+struct KnnShape {
+    int dp, nq, nw, wps;
+};
+static const KnnShape kShapes[] = {
+    {128, 1, 4, 3},  // 128 queries/WG, <=168 VGPRs, up to 3 WG/CU
+    {128, 1, 8, 4},  // 256 queries/WG, <=128 VGPRs, up to 2 WG/CU
+    {128, 2, 4, 2},  // 256 queries/WG, <=256 VGPRs, up to 2 WG/CU
+    {256, 1, 8, 2},  // 256 queries/WG, <=256 VGPRs, 1 WG/CU
+};
+
+static size_t knn_lds_bytes(const KnnShape &sh, int k) {
+    const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
+    return (size_t)2 * 32 * 64 * 4 + (size_t)k * qw * 8 + (size_t)QCAP * sh.nq * nt * 8;
+}
+
+static int knn_wg_per_cu(const KnnShape &sh, int k) {
+    const int by_lds = (int)((size_t)160 * 1024 / knn_lds_bytes(sh, k));
+    const int by_regs = (sh.wps * 4) / sh.nw;  // waves per CU the register budget allows / waves per WG
+    return std::max(0, std::min(by_lds, std::max(by_regs, 1)));
+}
+
+static int knn_choose_shape(int dp, int k) {
+    if (const char *e = getenv("FDR_KNN_SHAPE")) {  // development knob: index into kShapes
+        const int i = atoi(e);
+        if (i >= 0 && i < (int)(sizeof(kShapes) / sizeof(kShapes[0])) && kShapes[i].dp == dp &&
+            knn_wg_per_cu(kShapes[i], k) > 0)
+            return i;
+    }
+    if (dp == 256) return 3;
+    // d <= 128: the 8-wave shape keeps 4 waves/SIMD while two workgroups fit in LDS; for larger k
+    // only one fits and the 256-VGPR shapes are the better use of the CU
+    if (knn_wg_per_cu(kShapes[1], k) >= 2) return 1;
+    return 2;
+}
+
 struct KnnPlan {
-    int nqb, nseg, seg_len, nq_pad;
+    int shape, qw, nqb, nseg, seg_len, nq_pad;
     size_t bits_bytes;     // packed zero-target flags, at the start of the workspace
     size_t partial_bytes;  // per-segment top-k lists
     size_t total_bytes;
 };
 
-static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int k) {
+static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
     KnnPlan p;
-    p.nqb = (int)((nq + 255) / 256);
-    p.nq_pad = p.nqb * 256;
+    p.shape = knn_choose_shape(fdr_padded_dim(d), k);
+    const KnnShape &sh = kShapes[p.shape];
+    p.qw = 32 * sh.nq * sh.nw;
+    p.nqb = (int)((nq + p.qw - 1) / p.qw);
+    p.nq_pad = p.nqb * p.qw;
     // Split the targets into nseg segments so that the grid (nqb x nseg workgroups of equal cost)
     // fills the chip's workgroup slots in whole "rounds": pick the nseg with the best fill
     // efficiency, charging ~1.5 % per extra segment for the top-k warm-up each segment repeats.
-    const long long slots = (long long)ctx->num_cus * 2;
+    const long long slots = (long long)ctx->num_cus * std::max(1, knn_wg_per_cu(sh, k));
     const long long max_seg = std::max<long long>(1, std::min<long long>(nt / 2048, 24));
     long long nseg = 1;
     double best_score = -1.0;
@@ -826,9 +860,8 @@ static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int k) {
 
 FDR_EXPORT size_t fdr_knn_workspace_bytes(fdr_ctx *ctx, int64_t nq, int64_t nt, int32_t d,
                                           int32_t k) {
-    (void)d;
-    if (!ctx || nq <= 0 || nt <= 0 || k <= 0) return 0;
-    return knn_plan(ctx, nq, nt, k).total_bytes;
+    if (!ctx || nq <= 0 || nt <= 0 || k <= 0 || k > FDR_MAX_K || fdr_padded_dim(d) < 0) return 0;
+    return knn_plan(ctx, nq, nt, d, k).total_bytes;
 }
 
 static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
@@ -844,7 +877,7 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     if (nq == 0) return FDR_OK;
     if (!d_Qhat || !d_qzero || !d_That || !d_tzero || !d_idx || !d_dist || !d_ws)
         return fail(FDR_E_ARG, "knn: null device pointer");
-    const KnnPlan p = knn_plan(ctx, nq, nt, k);
+    const KnnPlan p = knn_plan(ctx, nq, nt, d, k);
     if (ws_bytes < p.total_bytes)
         return fail(FDR_E_ARG, "knn: workspace %zu < required %zu bytes", ws_bytes, p.total_bytes);
     unsigned *d_bits = reinterpret_cast<unsigned *>(d_ws);
@@ -852,32 +885,29 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     hipLaunchKernelGGL(pack_zero_bits_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st,
                        d_tzero, (int)nt, d_bits);
     HIP_TRY(hipGetLastError());
-    // 2 stages x 8 KB | K x 256 keys | per-lane append queues (QCAP x 512 lanes... x 8 B = 16 KB)
-    const size_t lds = (size_t)2 * 32 * 64 * 4 + (size_t)k * 256 * 8 + (size_t)QCAP * 512 * 8;
+    const KnnShape &sh = kShapes[p.shape];
+    const size_t lds = knn_lds_bytes(sh, k);
     if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn: k=%d, d=%d needs %zu B of LDS (> 160 KiB)", k, d, lds);
     dim3 grid((unsigned)p.nqb, (unsigned)p.nseg);
     const char *dbg_env = getenv("FDR_KNN_DEBUG");  // development knob, see DESIGN.md
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
     int trc = timing_begin(ctx, FDR_KERNEL_KNN_TILE, st);
     if (trc) return trc;
-    const char *nq_env = getenv("FDR_KNN_NQ");  // development knob: query sets per wave at d <= 128
-    const int nq_sets = nq_env ? atoi(nq_env) : 1;
-    if (dp == 128 && nq_sets == 2) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<128, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((knn_tile_kernel<128, 2>), grid, dim3(256), lds, st, d_Qhat, d_qzero, (int)nq,
-                           d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial, dbg);
-    } else if (dp == 128) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<128, 1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((knn_tile_kernel<128, 1>), grid, dim3(512), lds, st, d_Qhat, d_qzero, (int)nq,
-                           d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial, dbg);
-    } else {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<256, 1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((knn_tile_kernel<256, 1>), grid, dim3(512), lds, st, d_Qhat, d_qzero, (int)nq,
-                           d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k, p.nq_pad, d_partial, dbg);
+#define FDR_LAUNCH_KNN(DP_, NQ_, NW_, WPS_)                                                          \
+    do {                                                                                             \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<DP_, NQ_, NW_, WPS_>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+        hipLaunchKernelGGL((knn_tile_kernel<DP_, NQ_, NW_, WPS_>), grid, dim3(64 * NW_), lds, st, d_Qhat, \
+                           d_qzero, (int)nq, d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k,     \
+                           p.nq_pad, d_partial, dbg);                                                \
+    } while (0)
+    switch (p.shape) {
+        case 0: FDR_LAUNCH_KNN(128, 1, 4, 3); break;
+        case 1: FDR_LAUNCH_KNN(128, 1, 8, 4); break;
+        case 2: FDR_LAUNCH_KNN(128, 2, 4, 2); break;
+        default: FDR_LAUNCH_KNN(256, 1, 8, 2); break;
     }
+#undef FDR_LAUNCH_KNN
     HIP_TRY(hipGetLastError());
 #ifdef FDR_DEBUG_COUNTERS
     if (dbg & 2) {
