@@ -198,7 +198,11 @@ __device__ __forceinline__ float sim_floor(float tau) {
 
 // zero-row byte flags -> one bit per target row (bit r of word w = row 32w + r)
 __global__ __launch_bounds__(256) void pack_zero_bits_kernel(const unsigned char *__restrict__ zero,
-                                                             int n, unsigned *__restrict__ bits) {
+                                                             int n, unsigned *__restrict__ bits,
+                                                             unsigned *__restrict__ tau_shared,
+                                                             int n_shared) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_shared; i += gridDim.x * 256)
+        tau_shared[i] = 0x7F800000u;  // +inf: no segment has a full list yet
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool z = i < n && zero[i] != 0;
     const u64 m = __ballot(z);
@@ -227,16 +231,40 @@ __device__ unsigned long long g_dbg_counters[8];
 
 struct TopkState {
     u64 taukey;   // maximum key of the query's list (both lanes of the query hold the same value)
-    float tau;    // its distance part
+    float tau;    // admission bound: min(distance part of taukey, cross-segment bound), see topk_share
     float cfloor; // sim_floor(tau)
-    int taupos;   // its position in the list
+    int taupos;   // position of taukey in the list
     int qcnt;     // entries in this LANE's append queue
 };
 
+// Cross-segment bound.  Workgroups that search different target segments for the same queries
+// publish the k-th best distance of their (full) list with a relaxed device-scope atomicMin on one
+// word per query and adopt the minimum any segment has published.  Every published value is an upper
+// bound of the query's final k-th best distance D, so a candidate with dist > bound can never be in
+// the final top-k; candidates with dist == bound are kept (ties are decided by index in the merge):
+// the admission test is dist < nextup(bound).  A stale or missing value only admits more candidates,
+// so the result does not depend on scheduling, timing or placement.
+__device__ __forceinline__ float topk_share(unsigned *__restrict__ slot, const u64 taukey, const int h) {
+    const unsigned mine = (unsigned)(taukey >> 32);  // 0x7F800000 while the list still has empty slots
+    unsigned seen = mine;
+    if (h == 0) {
+        const unsigned old = mine < 0x7F800000u
+                                 ? __hip_atomic_fetch_min(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen = old < mine ? old : mine;
+    }
+    seen = __shfl(seen, (threadIdx.x & 31), 64) ;  // lane j (h == 0) of this query holds the value
+    // strict bound: the list's own maximum admits dist < tau; a foreign bound admits dist <= bound
+    const float own = __uint_as_float(mine);
+    const float foreign = seen < 0x7F800000u ? __uint_as_float(seen + 1u) : __builtin_inff();
+    return fminf(own, foreign);
+}
+
 template <int NT, int QW>
 __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lists,
-                                             u64 *__restrict__ queue, const int ql, const int K,
-                                             const int tid, const int h, const bool dbgc) {
+                                             u64 *__restrict__ queue, unsigned *__restrict__ shared,
+                                             const int ql, const int K, const int tid, const int h,
+                                             const bool dbgc) {
     DBG_COUNT(2);
     const int cnt_me = st.qcnt;
     const int cnt_other = __shfl_xor(cnt_me, 32);
@@ -275,11 +303,11 @@ __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lis
                     }
                     st.taukey = best;
                     st.taupos = bp;
-                    st.tau = __uint_as_float((unsigned)(best >> 32));
                 }
             }
         }
     }
+    st.tau = topk_share(shared, st.taukey, h);
     st.cfloor = sim_floor(st.tau);
     st.qcnt = 0;
     return st;
@@ -289,9 +317,9 @@ __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lis
 // (r&3) + 8*(r>>2) + 4*h; rows >= nvalid do not exist (last tile of a segment only).
 template <int NT, int QW>
 __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64 *__restrict__ lists,
-                                            u64 *__restrict__ queue, const int ql, const int K,
-                                            const int tid, const int h, int idx0, int nvalid,
-                                            const bool dbgc) {
+                                            u64 *__restrict__ queue, unsigned *__restrict__ shared,
+                                            const int ql, const int K, const int tid, const int h,
+                                            int idx0, int nvalid, const bool dbgc) {
     // this block is cold: keep its address / index arithmetic from being hoisted into the hot loop
     asm volatile("" : "+s"(idx0), "+s"(nvalid));
     unsigned todo = 0xffffu;
@@ -322,7 +350,7 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
             }
         }
         if (!__any(ovf != 0u)) break;
-        st = topk_flush<NT, QW>(st, lists, queue, ql, K, tid, h, dbgc);
+        st = topk_flush<NT, QW>(st, lists, queue, shared, ql, K, tid, h, dbgc);
         todo = ovf;
     }
 }
@@ -335,7 +363,8 @@ template <int DP, int NQ, int NW, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
     const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
     const float *__restrict__ Th, const unsigned *__restrict__ tzbits, int nt, int t_base,
-    int seg_len, int K, int nq_pad, u64 *__restrict__ partial, int dbg) {
+    int seg_len, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared,
+    int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 64 * NW;              // threads per workgroup
     constexpr int QW = 32 * NQ * NW;         // queries per workgroup
@@ -353,11 +382,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
     float b[NQ][DP / 2];
     bool qz[NQ];
     int ql[NQ];
+    unsigned *shared[NQ];  // this query's cross-segment bound word
     bool any_qz = false;
 #pragma unroll
     for (int s = 0; s < NQ; ++s) {
         ql[s] = (wave * NQ + s) * 32 + j;
         const int qg = blockIdx.x * QW + ql[s];
+        shared[s] = tau_shared + qg;
         const int qrow = qg < nq ? qg : nq - 1;
         qz[s] = qzero[qrow] != 0;
         any_qz = any_qz || __any(qz[s]);
@@ -466,8 +497,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
                         continue;
                     }
                     if (__any(mx > st[s].cfloor))
-                        topk_append<NT, QW>(acc[s], st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h,
-                                        t_base + tile_row0, t_end - tile_row0, (dbg & 2) != 0);
+                        topk_append<NT, QW>(acc[s], st[s], lists, queues + s * QCAP * NT, shared[s], ql[s],
+                                            K, tid, h, t_base + tile_row0, t_end - tile_row0, (dbg & 2) != 0);
+                    if ((t & 31) == 31 && !(dbg & 4)) {  // refresh the cross-segment bound now and then
+                        st[s].tau = topk_share(shared[s], st[s].taukey, h);
+                        st[s].cfloor = sim_floor(st[s].tau);
+                    }
                 }
             }
             __syncthreads();  // (hipcc drains vmcnt before the barrier: the next stage is in LDS)
@@ -478,7 +513,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
 #pragma unroll
     for (int s = 0; s < NQ; ++s)
         if (__any(st[s].qcnt > 0))
-            st[s] = topk_flush<NT, QW>(st[s], lists, queues + s * QCAP * NT, ql[s], K, tid, h, (dbg & 2) != 0);
+            st[s] = topk_flush<NT, QW>(st[s], lists, queues + s * QCAP * NT, shared[s], ql[s], K, tid, h,
+                                       (dbg & 2) != 0);
     __syncthreads();
     {
         u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * QW) * K;
@@ -808,15 +844,16 @@ static int knn_choose_shape(int dp, int k) {
             return i;
     }
     if (dp == 256) return 3;
-    // d <= 128: the 8-wave shape keeps 4 waves/SIMD while two workgroups fit in LDS; for larger k
-    // only one fits and the 256-VGPR shapes are the better use of the CU
-    if (knn_wg_per_cu(kShapes[1], k) >= 2) return 1;
+    // d <= 128: the 4-wave / 128-query shape (no spills at 168 VGPRs, finest work granularity) while
+    // at least two workgroups fit in LDS; for larger k the 2-chain 256-VGPR shape
+    if (knn_wg_per_cu(kShapes[0], k) >= 2) return 0;
     return 2;
 }
 
 struct KnnPlan {
     int shape, qw, nqb, nseg, seg_len, nq_pad;
     size_t bits_bytes;     // packed zero-target flags, at the start of the workspace
+    size_t shared_bytes;   // one cross-segment bound word per (padded) query
     size_t partial_bytes;  // per-segment top-k lists
     size_t total_bytes;
 };
@@ -854,7 +891,8 @@ static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k
     p.seg_len = (int)seg_len;
     p.partial_bytes = (size_t)p.nseg * p.nq_pad * (size_t)k * sizeof(u64);
     p.bits_bytes = ((size_t)((nt + 31) / 32) * 4 + 255) / 256 * 256;
-    p.total_bytes = p.bits_bytes + p.partial_bytes;
+    p.shared_bytes = ((size_t)p.nq_pad * 4 + 255) / 256 * 256;
+    p.total_bytes = p.bits_bytes + p.shared_bytes + p.partial_bytes;
     return p;
 }
 
@@ -881,9 +919,10 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     if (ws_bytes < p.total_bytes)
         return fail(FDR_E_ARG, "knn: workspace %zu < required %zu bytes", ws_bytes, p.total_bytes);
     unsigned *d_bits = reinterpret_cast<unsigned *>(d_ws);
-    u64 *d_partial = reinterpret_cast<u64 *>(static_cast<char *>(d_ws) + p.bits_bytes);
+    unsigned *d_shared = reinterpret_cast<unsigned *>(static_cast<char *>(d_ws) + p.bits_bytes);
+    u64 *d_partial = reinterpret_cast<u64 *>(static_cast<char *>(d_ws) + p.bits_bytes + p.shared_bytes);
     hipLaunchKernelGGL(pack_zero_bits_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st,
-                       d_tzero, (int)nt, d_bits);
+                       d_tzero, (int)nt, d_bits, d_shared, p.nq_pad);
     HIP_TRY(hipGetLastError());
     const KnnShape &sh = kShapes[p.shape];
     const size_t lds = knn_lds_bytes(sh, k);
@@ -899,7 +938,7 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
         hipLaunchKernelGGL((knn_tile_kernel<DP_, NQ_, NW_, WPS_>), grid, dim3(64 * NW_), lds, st, d_Qhat, \
                            d_qzero, (int)nq, d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k,     \
-                           p.nq_pad, d_partial, dbg);                                                \
+                           p.nq_pad, d_partial, d_shared, dbg);                                      \
     } while (0)
     switch (p.shape) {
         case 0: FDR_LAUNCH_KNN(128, 1, 4, 3); break;
