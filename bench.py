@@ -44,10 +44,24 @@ def parse_args():
     return p.parse_args()
 
 
+def cpu_budget():
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(s, P, d, k, target_seconds):
     """Time the CPU oracle on a bounded sample: embed + normalise ALL rows (they are the targets),
     then k-NN for as many query rows as fit the time budget; extrapolate linearly in queries."""
     import numpy as np
+    os.environ.setdefault("OMP_NUM_THREADS", str(cpu_budget()))
     from oracle import oracle as O
     cores = O.lib().orc_num_threads()
     n = len(s["indptr"]) - 1
@@ -57,7 +71,8 @@ def cpu_baseline(s, P, d, k, target_seconds):
     t0 = time.perf_counter()
     Eh, _, zero = O.normalize(E)
     t_norm = time.perf_counter() - t0
-    probe = min(n, 256)
+    probe = min(n, max(256, 64 * cores))
+    O.knn_normalized(Eh[:64], zero[:64], Eh, zero, k)  # warm the thread pool / page in the targets
     t0 = time.perf_counter()
     O.knn_normalized(Eh[:probe], zero[:probe], Eh, zero, k)
     t_probe = time.perf_counter() - t0
