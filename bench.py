@@ -61,8 +61,8 @@ def cpu_baseline(s, P, d, k, target_seconds):
     """Time the CPU oracle on a bounded sample: embed + normalise ALL rows (they are the targets),
     then k-NN for as many query rows as fit the time budget; extrapolate linearly in queries."""
     import numpy as np
-    os.environ.setdefault("OMP_NUM_THREADS", str(cpu_budget()))
     from oracle import oracle as O
+    O.set_num_threads(cpu_budget())  # (libgomp is already loaded by torch: the env var would be too late)
     cores = O.lib().orc_num_threads()
     n = len(s["indptr"]) - 1
     t0 = time.perf_counter()
@@ -175,6 +175,16 @@ def main():
         achieved = flops / (knn_ms * 1e-3) / 1e12 if knn_ms > 0 else 0.0
         nnz_loc = int(ix.size)
         embed_bytes = 4.0 * nnz_loc + 8.0 * nloc + 4.0 * nloc * d
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as the
+        # gfx950 guide prescribes + WRITE_SIZE); only valid for the workload it was collected on
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_summary.json")) as f:
+                prof = json.load(f)
+            if (R, d, k, world, args.doubling) == (100_000, 128, 20, 1, False):
+                traffic = prof["pmc_per_launch_avg"]["knn_tile_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         result = {
             "metric": "read-pairs/sec (overlap candidates)", "value": value, "unit": "read-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -188,7 +198,9 @@ def main():
                        "zero_row_fraction_sample": zero_frac, "self_check": ok},
             "roofline": {"kernel": "knn_tile_kernel<%d>" % ctx.padded_dim(d), "bound": "mfma",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": "profiles/r1_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                           "bytes per launch)" if traffic else None,
                          "flops_per_launch": flops, "avg_launch_ms": knn_ms},
             "kernels_ms": kernel_ms,
             "embed_roofline": {"bound": "hbm", "achieved": embed_bytes / (kernel_ms["embed_csr"] * 1e-3) / 1e9

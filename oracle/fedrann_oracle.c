@@ -227,6 +227,14 @@ ORC_API float orc_pair_dist(const float *a, const float *b, int32_t d, int az, i
     return cos_dist(chain_dot(a, b, d), az, bz);
 }
 
+ORC_API void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORC_API int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

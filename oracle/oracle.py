@@ -47,8 +47,15 @@ def lib():
         L.orc_pair_dist.argtypes = [vp, vp, i32, ctypes.c_int, ctypes.c_int]
         L.orc_pair_dist.restype = ctypes.c_float
         L.orc_num_threads.restype = ctypes.c_int
+        L.orc_set_num_threads.argtypes = [ctypes.c_int]
+        L.orc_set_num_threads.restype = None
         _LIB = L
     return _LIB
+
+
+def set_num_threads(n):
+    """Threads the OpenMP loops of the oracle use (bench.py sets the cgroup CPU budget)."""
+    lib().orc_set_num_threads(int(n))
 
 
 def _p(a):
