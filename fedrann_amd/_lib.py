@@ -18,7 +18,7 @@ SYMBOLS = (
 )
 FDR_MAX_K = 64
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge")
-FDR_MAX_DIM = 256
+FDR_MAX_DIM = 512
 
 
 class FedrannHipError(RuntimeError):

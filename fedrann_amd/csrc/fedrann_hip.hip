@@ -640,6 +640,7 @@ FDR_EXPORT int fdr_padded_dim(int d) {
     if (d <= 0) return FDR_E_ARG;
     if (d <= 128) return 128;
     if (d <= 256) return 256;
+    if (d <= 512) return 512;
     return FDR_E_ARG;
 }
 
@@ -778,16 +779,18 @@ static int launch_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *d_indptr,
     const int grid = (int)std::min<long long>(blocks_needed, (long long)ctx->num_cus * 8 * 4);
     int trc = timing_begin(ctx, FDR_KERNEL_EMBED, st);
     if (trc) return trc;
+#define FDR_LAUNCH_EMBED(DP_)                                                                   \
+    hipLaunchKernelGGL(embed_csr_kernel<DP_>, dim3(grid), dim3(256), 0, st, (long long)n_rows,  \
+                       (const long long *)d_indptr, d_indices, ctx->n_features,                 \
+                       (const uint2 *)ctx->ftab.p, (const int *)ctx->crow.p,                    \
+                       (const uint2 *)ctx->ent.p, ctx->d, d_E)
     if (dp == 128)
-        hipLaunchKernelGGL(embed_csr_kernel<128>, dim3(grid), dim3(256), 0, st, (long long)n_rows,
-                           (const long long *)d_indptr, d_indices, ctx->n_features,
-                           (const uint2 *)ctx->ftab.p, (const int *)ctx->crow.p,
-                           (const uint2 *)ctx->ent.p, ctx->d, d_E);
+        FDR_LAUNCH_EMBED(128);
+    else if (dp == 256)
+        FDR_LAUNCH_EMBED(256);
     else
-        hipLaunchKernelGGL(embed_csr_kernel<256>, dim3(grid), dim3(256), 0, st, (long long)n_rows,
-                           (const long long *)d_indptr, d_indices, ctx->n_features,
-                           (const uint2 *)ctx->ftab.p, (const int *)ctx->crow.p,
-                           (const uint2 *)ctx->ent.p, ctx->d, d_E);
+        FDR_LAUNCH_EMBED(512);
+#undef FDR_LAUNCH_EMBED
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_EMBED, st);
 }
@@ -798,7 +801,7 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
     if (dp < 0) return fail(FDR_E_ARG, "normalize: dimension %d unsupported (1..%d)", d, FDR_MAX_DIM);
     if (n_rows < 0) return fail(FDR_E_ARG, "normalize: n_rows < 0");
     if (n_rows == 0) return FDR_OK;
-    const int rb = dp == 128 ? 64 : 32;
+    const int rb = dp == 128 ? 64 : (dp == 256 ? 32 : 16);
     const long long grid = (n_rows + rb - 1) / rb;
     if (grid > 0x7fffffffll) return fail(FDR_E_ARG, "normalize: too many rows");
     int trc = timing_begin(ctx, FDR_KERNEL_NORMALIZE, st);
@@ -806,8 +809,11 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
     if (dp == 128)
         hipLaunchKernelGGL((normalize_rows_kernel<128, 64>), dim3((unsigned)grid), dim3(64), 0, st,
                            d_E, (long long)n_rows, d, d_Ehat, d_zero);
-    else
+    else if (dp == 256)
         hipLaunchKernelGGL((normalize_rows_kernel<256, 32>), dim3((unsigned)grid), dim3(64), 0, st,
+                           d_E, (long long)n_rows, d, d_Ehat, d_zero);
+    else
+        hipLaunchKernelGGL((normalize_rows_kernel<512, 16>), dim3((unsigned)grid), dim3(64), 0, st,
                            d_E, (long long)n_rows, d, d_Ehat, d_zero);
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_NORMALIZE, st);
@@ -823,6 +829,7 @@ static const KnnShape kShapes[] = {
     {128, 1, 8, 4},  // 256 queries/WG, <=128 VGPRs, up to 2 WG/CU
     {128, 2, 4, 2},  // 256 queries/WG, <=256 VGPRs, up to 2 WG/CU
     {256, 1, 8, 2},  // 256 queries/WG, <=256 VGPRs, 1 WG/CU
+    {512, 1, 4, 1},  // 128 queries/WG, one wave per SIMD: 512 registers per lane (256 of them queries)
 };
 
 static size_t knn_lds_bytes(const KnnShape &sh, int k) {
@@ -844,6 +851,7 @@ static int knn_choose_shape(int dp, int k) {
             return i;
     }
     if (dp == 256) return 3;
+    if (dp == 512) return 4;
     // d <= 128: the 4-wave / 128-query shape (no spills at 168 VGPRs, finest work granularity) while
     // at least two workgroups fit in LDS; for larger k the 2-chain 256-VGPR shape
     if (knn_wg_per_cu(kShapes[0], k) >= 2) return 0;
@@ -944,7 +952,8 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
         case 0: FDR_LAUNCH_KNN(128, 1, 4, 3); break;
         case 1: FDR_LAUNCH_KNN(128, 1, 8, 4); break;
         case 2: FDR_LAUNCH_KNN(128, 2, 4, 2); break;
-        default: FDR_LAUNCH_KNN(256, 1, 8, 2); break;
+        case 3: FDR_LAUNCH_KNN(256, 1, 8, 2); break;
+        default: FDR_LAUNCH_KNN(512, 1, 4, 1); break;
     }
 #undef FDR_LAUNCH_KNN
     HIP_TRY(hipGetLastError());

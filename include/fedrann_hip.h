@@ -39,7 +39,7 @@ extern "C" {
 #define FDR_E_STATE (-5)   /* call order (e.g. embed before a projection was loaded) */
 
 #define FDR_MAX_K 64       /* neighbours per row (self included) supported by the top-k kernel */
-#define FDR_MAX_DIM 256    /* embedding dimension supported by the k-NN kernel this round */
+#define FDR_MAX_DIM 512    /* embedding dimension supported by the k-NN kernel (reference default: 500) */
 
 typedef struct fdr_ctx fdr_ctx;
 
@@ -50,7 +50,7 @@ const char *fdr_last_error(void);
 /* "name|gcnArch|CUs|HBM bytes" of the context's device, NUL-terminated into buf. */
 int fdr_device_info(fdr_ctx *ctx, char *buf, int buflen);
 /* Padded row length (floats) of the internal normalised-embedding layout for dimension d:
- * 128 for d <= 128, 256 for d <= 256; negative if d is unsupported. */
+ * 128 for d <= 128, 256 for d <= 256, 512 for d <= 512; negative if d is unsupported. */
 int fdr_padded_dim(int d);
 
 /* ---- projection (replaces handing `precompute_matrix` to get_feature_matrix,

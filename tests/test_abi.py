@@ -32,7 +32,8 @@ def test_constants_match_header():
 def test_padded_dim_needs_no_gpu(lib):
     assert lib.fdr_padded_dim(1) == 128 and lib.fdr_padded_dim(128) == 128
     assert lib.fdr_padded_dim(129) == 256 and lib.fdr_padded_dim(256) == 256
-    assert lib.fdr_padded_dim(257) < 0 and lib.fdr_padded_dim(0) < 0
+    assert lib.fdr_padded_dim(257) == 512 and lib.fdr_padded_dim(500) == 512
+    assert lib.fdr_padded_dim(513) < 0 and lib.fdr_padded_dim(0) < 0
 
 
 def test_no_gpu_fails_loudly(lib):

@@ -37,7 +37,8 @@ def test_embed_matches_reference_golden(ctx, tag):
     assert np.array_equal(_bits(E), E_bits)
 
 
-@pytest.mark.parametrize("R,d,m", [(3000, 128, 200), (1500, 64, 50), (800, 200, 120), (500, 256, 400)])
+@pytest.mark.parametrize("R,d,m", [(3000, 128, 200), (1500, 64, 50), (800, 200, 120), (500, 256, 400),
+                                   (600, 500, 300)])
 def test_embed_matches_oracle_on_synthetic(ctx, oracle, R, d, m):
     s = synth(R, seed=R + d, m=m)
     P = build_precompute_matrix(s["counts"], d)
@@ -78,7 +79,7 @@ def test_embed_dense_projection_rows(ctx, oracle):
 # ---- k-NN ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,d,k", [(2000, 128, 20), (777, 128, 20), (3000, 64, 20), (1200, 200, 50),
                                    (900, 256, 50), (300, 128, 1), (513, 100, 64), (64, 128, 64),
-                                   (33, 7, 33)])
+                                   (33, 7, 33), (1100, 500, 50), (700, 512, 20), (400, 300, 64)])
 def test_knn_dense_random_matches_oracle(ctx, oracle, n, d, k):
     E = np.random.default_rng(n + d + k).standard_normal((n, d)).astype(np.float32)
     _assert_knn_equal(ctx.knn(E, k), oracle.knn(E, k))
@@ -108,6 +109,17 @@ def test_knn_heavy_ties(ctx, oracle):
     E = E[rng.permutation(E.shape[0])]
     for k in (20, 50):
         _assert_knn_equal(ctx.knn(E, k), oracle.knn(E, k))
+
+
+def test_reference_default_shape_d500_k50(ctx, oracle):
+    # the reference CLI defaults: -n 500, --nndescent-n-neighbors 50, fwd/rev doubled rows
+    s = synth(2500, seed=7, doubling=True)
+    P = build_precompute_matrix(s["counts"], 500)
+    ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], 500)
+    idx, dist, E = ctx.embed_knn(s["indptr"], s["indices"], 50, return_embedding=True)
+    want_E = oracle.embed(s["indptr"], s["indices"], (P.indptr, P.indices, P.data), s["n_features"], 500)
+    assert np.array_equal(_bits(E), _bits(want_E))
+    _assert_knn_equal((idx, dist), oracle.knn(want_E, 50))
 
 
 def test_knn_synthetic_pipeline_config2_shape_small(ctx, oracle):
@@ -153,7 +165,7 @@ def test_errors_are_raised_not_swallowed(ctx):
     with pytest.raises(_lib.FedrannHipError):
         ctx.knn(E, 0)
     with pytest.raises(_lib.FedrannHipError):
-        ctx.knn(np.zeros((100, 300), np.float32), 5)  # d > FDR_MAX_DIM
+        ctx.knn(np.zeros((100, 600), np.float32), 5)  # d > FDR_MAX_DIM
     with pytest.raises(_lib.FedrannHipError):
         ctx.knn(np.zeros((100, 16), np.float32), 65)  # k > FDR_MAX_K
     fresh = _lib.Context(0)
