@@ -358,7 +358,7 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
 // DP: padded embedding length.  NQ: 32-query sets per wave (independent MFMA accumulator chains
 // that share every A fragment).  NW: waves per workgroup; a workgroup owns QW = 32*NQ*NW queries.
 // WPS: waves per SIMD the register budget is sized for.
-// LDS: 2 stages of 32 target rows x 64 components (16 KB) | lists K x QW keys | queues.
+// LDS: 3-stage ring of 32 target rows x 64 components (24 KB) | lists K x QW keys | queues.
 template <int DP, int NQ, int NW, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
     const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
@@ -371,8 +371,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
     constexpr int NCH = DP / 64;             // 64-component K-chunks per tile
     constexpr int STAGE_BYTES = 32 * 64 * 4; // one stage = 32 target rows x 64 components (8 KB)
     constexpr int SLOTS = 16;                // 16-byte slots per staged row
-    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES);                         // K * QW keys
-    u64 *queues = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES + (size_t)K * QW * 8);  // NQ*QCAP*NT
+    constexpr int NSTAGE = 3;                // LDS ring: stage it lives in buffer it % 3
+    u64 *lists = reinterpret_cast<u64 *>(smem + NSTAGE * STAGE_BYTES);                         // K * QW keys
+    u64 *queues = reinterpret_cast<u64 *>(smem + NSTAGE * STAGE_BYTES + (size_t)K * QW * 8);  // NQ*QCAP*NT
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -382,13 +383,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
     float b[NQ][DP / 2];
     bool qz[NQ];
     int ql[NQ];
-    unsigned *shared[NQ];  // this query's cross-segment bound word
+    int qslot[NQ];  // index of this query's cross-segment bound word
     bool any_qz = false;
 #pragma unroll
     for (int s = 0; s < NQ; ++s) {
         ql[s] = (wave * NQ + s) * 32 + j;
         const int qg = blockIdx.x * QW + ql[s];
-        shared[s] = tau_shared + qg;
+        qslot[s] = qg;
         const int qrow = qg < nq ? qg : nq - 1;
         qz[s] = qzero[qrow] != 0;
         any_qz = any_qz || __any(qz[s]);
@@ -407,10 +408,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
 #pragma unroll
     for (int s = 0; s < NQ; ++s) {
         st[s].taukey = KEY_INF;
-        st[s].tau = __builtin_inff();
-        st[s].cfloor = -__builtin_inff();
         st[s].taupos = 0;
         st[s].qcnt = 0;
+        st[s].tau = topk_share((tau_shared + qslot[s]), KEY_INF, h);  // other segments may already have a bound
+        st[s].cfloor = sim_floor(st[s].tau);
     }
 
     const int t_begin = blockIdx.y * seg_len;  // multiple of 32
@@ -439,8 +440,29 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
         }
     };
 
+    // The ring runs two stages ahead: stage it+2 is issued at the top of iteration it, and the wait
+    // at the bottom leaves exactly that newest stage in flight (counted vmcnt, raw s_barrier: a
+    // __syncthreads() here would make hipcc drain vmcnt(0) and serialise the DMA with the MFMAs).
+    constexpr int DMA_PER_STAGE = (NPIECE + NW - 1) / NW;  // LDS-DMA instructions per wave per stage
+    static_assert(NPIECE % NW == 0, "every wave must issue the same number of LDS-DMA pieces");
+    auto wait_stage = [&]() {  // all but the newest stage's pieces of THIS wave have landed
+        if constexpr (DMA_PER_STAGE == 1)
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    };
+    auto ring_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
     if (nstages > 0) issue_stage(0, 0);
-    __syncthreads();
+    if (nstages > 1) issue_stage(1, 1);
+    if (nstages > 1)
+        wait_stage();
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // also publishes the list initialisation
 
     for (int t = 0; t < ntiles; ++t) {
         f32x16 acc[NQ];
@@ -451,8 +473,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int it = t * NCH + ch;
-            const int buf = it & 1;
-            if (it + 1 < nstages) issue_stage(it + 1, buf ^ 1);  // lands before the barrier below
+            const int buf = it % NSTAGE;
+            if (it + 2 < nstages) issue_stage(it + 2, (it + 2) % NSTAGE);
 
             // ---- 32 targets x (NQ x 32) queries x 64 components ----
             {
@@ -497,15 +519,20 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
                         continue;
                     }
                     if (__any(mx > st[s].cfloor))
-                        topk_append<NT, QW>(acc[s], st[s], lists, queues + s * QCAP * NT, shared[s], ql[s],
+                        topk_append<NT, QW>(acc[s], st[s], lists, queues + s * QCAP * NT, (tau_shared + qslot[s]), ql[s],
                                             K, tid, h, t_base + tile_row0, t_end - tile_row0, (dbg & 2) != 0);
                     if ((t & 31) == 31 && !(dbg & 4)) {  // refresh the cross-segment bound now and then
-                        st[s].tau = topk_share(shared[s], st[s].taukey, h);
+                        st[s].tau = topk_share((tau_shared + qslot[s]), st[s].taukey, h);
                         st[s].cfloor = sim_floor(st[s].tau);
                     }
                 }
             }
-            __syncthreads();  // (hipcc drains vmcnt before the barrier: the next stage is in LDS)
+            // stage it+1 must be complete (every wave's pieces) before anyone reads it
+            if (it + 2 < nstages)
+                wait_stage();
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ring_barrier();
         }
     }
 
@@ -513,7 +540,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
 #pragma unroll
     for (int s = 0; s < NQ; ++s)
         if (__any(st[s].qcnt > 0))
-            st[s] = topk_flush<NT, QW>(st[s], lists, queues + s * QCAP * NT, shared[s], ql[s], K, tid, h,
+            st[s] = topk_flush<NT, QW>(st[s], lists, queues + s * QCAP * NT, (tau_shared + qslot[s]), ql[s], K, tid, h,
                                        (dbg & 2) != 0);
     __syncthreads();
     {
@@ -834,7 +861,7 @@ static const KnnShape kShapes[] = {
 
 static size_t knn_lds_bytes(const KnnShape &sh, int k) {
     const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
-    return (size_t)2 * 32 * 64 * 4 + (size_t)k * qw * 8 + (size_t)QCAP * sh.nq * nt * 8;
+    return (size_t)3 * 32 * 64 * 4 + (size_t)k * qw * 8 + (size_t)QCAP * sh.nq * nt * 8;
 }
 
 static int knn_wg_per_cu(const KnnShape &sh, int k) {
