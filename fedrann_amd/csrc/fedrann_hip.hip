@@ -358,7 +358,7 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
 // DP: padded embedding length.  NQ: 32-query sets per wave (independent MFMA accumulator chains
 // that share every A fragment).  NW: waves per workgroup; a workgroup owns QW = 32*NQ*NW queries.
 // WPS: waves per SIMD the register budget is sized for.
-// LDS: 3-stage ring of 32 target rows x 64 components (24 KB) | lists K x QW keys | queues.
+// LDS: 2-stage ring of 32 target rows x 64 components (16 KB) | lists K x QW keys | queues.
 template <int DP, int NQ, int NW, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
     const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
     constexpr int NCH = DP / 64;             // 64-component K-chunks per tile
     constexpr int STAGE_BYTES = 32 * 64 * 4; // one stage = 32 target rows x 64 components (8 KB)
     constexpr int SLOTS = 16;                // 16-byte slots per staged row
-    constexpr int NSTAGE = 3;                // LDS ring: stage it lives in buffer it % 3
+    constexpr int NSTAGE = 2;                // LDS ring: stage it lives in buffer it % 2
     u64 *lists = reinterpret_cast<u64 *>(smem + NSTAGE * STAGE_BYTES);                         // K * QW keys
     u64 *queues = reinterpret_cast<u64 *>(smem + NSTAGE * STAGE_BYTES + (size_t)K * QW * 8);  // NQ*QCAP*NT
 
@@ -440,28 +440,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
         }
     };
 
-    // The ring runs two stages ahead: stage it+2 is issued at the top of iteration it, and the wait
-    // at the bottom leaves exactly that newest stage in flight (counted vmcnt, raw s_barrier: a
-    // __syncthreads() here would make hipcc drain vmcnt(0) and serialise the DMA with the MFMAs).
-    constexpr int DMA_PER_STAGE = (NPIECE + NW - 1) / NW;  // LDS-DMA instructions per wave per stage
-    static_assert(NPIECE % NW == 0, "every wave must issue the same number of LDS-DMA pieces");
-    auto wait_stage = [&]() {  // all but the newest stage's pieces of THIS wave have landed
-        if constexpr (DMA_PER_STAGE == 1)
-            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    };
-    auto ring_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
+    // Two-stage ring: stage it+1 is issued at the top of iteration it and must have landed by the
+    // barrier at its bottom (hipcc drains vmcnt before __syncthreads()).  A three-stage ring with a
+    // counted vmcnt and a raw s_barrier was measured and bought nothing here (three waves per SIMD
+    // already hide the DMA latency), so the simpler form stays.
     if (nstages > 0) issue_stage(0, 0);
-    if (nstages > 1) issue_stage(1, 1);
-    if (nstages > 1)
-        wait_stage();
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // also publishes the list initialisation
 
     for (int t = 0; t < ntiles; ++t) {
@@ -474,7 +457,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
         for (int ch = 0; ch < NCH; ++ch) {
             const int it = t * NCH + ch;
             const int buf = it % NSTAGE;
-            if (it + 2 < nstages) issue_stage(it + 2, (it + 2) % NSTAGE);
+            if (it + 1 < nstages) issue_stage(it + 1, (it + 1) % NSTAGE);
 
             // ---- 32 targets x (NQ x 32) queries x 64 components ----
             {
@@ -527,12 +510,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
                     }
                 }
             }
-            // stage it+1 must be complete (every wave's pieces) before anyone reads it
-            if (it + 2 < nstages)
-                wait_stage();
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ring_barrier();
+            __syncthreads();  // stage it+1 is complete (every wave's pieces) before anyone reads it
         }
     }
 
@@ -861,7 +839,7 @@ static const KnnShape kShapes[] = {
 
 static size_t knn_lds_bytes(const KnnShape &sh, int k) {
     const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
-    return (size_t)3 * 32 * 64 * 4 + (size_t)k * qw * 8 + (size_t)QCAP * sh.nq * nt * 8;
+    return (size_t)2 * 32 * 64 * 4 + (size_t)k * qw * 8 + (size_t)QCAP * sh.nq * nt * 8;
 }
 
 static int knn_wg_per_cu(const KnnShape &sh, int k) {
