@@ -157,6 +157,28 @@ def test_knn_full_size_properties_and_sampled_oracle(ctx, oracle):
     _assert_knn_equal((idx[rows], dist[rows]), (wi, wd))
 
 
+def test_knn_one_million_rows_sampled_oracle(ctx, oracle):
+    """BASELINE config 3 (1M rows, d=128, k=20, ~6 non-zeros per embedding row => heavy ties, ~2 %
+    all-zero rows): exact oracle agreement on a sample of query rows + whole-result properties."""
+    s = synth(1_000_000, seed=602)
+    P = build_precompute_matrix(s["counts"], 128)
+    ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], 128)
+    idx, dist, E = ctx.embed_knn(s["indptr"], s["indices"], 20, return_embedding=True)
+    n = E.shape[0]
+    key = _bits(dist).astype(np.uint64) << np.uint64(32) | idx.astype(np.uint64)
+    assert np.all(key[:, 1:] > key[:, :-1])
+    assert idx.min() >= 0 and idx.max() < n and dist.min() >= 0 and dist.max() <= 1
+    rng = np.random.default_rng(3)
+    zero_rows = np.flatnonzero(np.abs(E).sum(1) == 0)
+    rows = np.unique(np.concatenate([rng.choice(n, size=320, replace=False), zero_rows[:32],
+                                     np.array([0, 1, n - 2, n - 1])]))
+    want_E = oracle.embed(s["indptr"], s["indices"], (P.indptr, P.indices, P.data), s["n_features"], 128)
+    assert np.array_equal(_bits(E), _bits(want_E))
+    Eh, _, zero = oracle.normalize(E)
+    wi, wd = oracle.knn_normalized(Eh[rows], zero[rows], Eh, zero, 20)
+    _assert_knn_equal((idx[rows], dist[rows]), (wi, wd))
+
+
 # ---- error behaviour -----------------------------------------------------------------------------
 def test_errors_are_raised_not_swallowed(ctx):
     E = np.zeros((10, 16), np.float32)
