@@ -336,9 +336,13 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
         unsigned ovf = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (acc[r] > st.cfloor && ((todo >> r) & 1u)) {
-                const float dist = dist_from_sim(acc[r]);
-                if (dist < st.tau) {
+            if (acc[r] > st.cfloor) {
+                // everything below is kept inside this (rarely taken) block: the asm makes the
+                // candidate opaque so that hipcc cannot evaluate the block's arithmetic eagerly
+                float a = acc[r];
+                asm volatile("" : "+v"(a));
+                const float dist = dist_from_sim(a);
+                if (((todo >> r) & 1u) && dist < st.tau) {
                     if (st.qcnt < QCAP) {
                         queue[st.qcnt * NT + tid] =
                             ((u64)__float_as_uint(dist) << 32) | (unsigned)(idxh + (r & 3) + 8 * (r >> 2));
