@@ -221,6 +221,12 @@ __global__ __launch_bounds__(256) void pack_zero_bits_kernel(const unsigned char
 // query rescan the list together.  Exactness: keys order by (dist, idx); a rejected candidate has
 // dist >= tau.dist and a larger index than every listed key, so it can never belong to the top-k.
 #define QCAP 4
+#define FDR_MAX_SEG 48
+
+// Target segment boundaries (in rows, multiples of 32 except the last): segment s = [b[s], b[s+1]).
+struct SegBounds {
+    int b[FDR_MAX_SEG + 1];
+};
 
 #ifdef FDR_DEBUG_COUNTERS  // development build only: event counters read back with FDR_KNN_DEBUG=2
 __device__ unsigned long long g_dbg_counters[8];
@@ -367,7 +373,7 @@ template <int DP, int NQ, int NW, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
     const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
     const float *__restrict__ Th, const unsigned *__restrict__ tzbits, int nt, int t_base,
-    int seg_len, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared,
+    SegBounds segs, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared,
     int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 64 * NW;              // threads per workgroup
@@ -418,8 +424,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
         st[s].cfloor = sim_floor(st[s].tau);
     }
 
-    const int t_begin = blockIdx.y * seg_len;  // multiple of 32
-    const int t_end = min(nt, t_begin + seg_len);
+    const int t_begin = segs.b[blockIdx.y];  // multiple of 32
+    const int t_end = min(nt, segs.b[blockIdx.y + 1]);
     const int ntiles = (t_end - t_begin + 31) >> 5;
     const int nstages = ntiles * NCH;
 
@@ -868,44 +874,123 @@ static int knn_choose_shape(int dp, int k) {
 }
 
 struct KnnPlan {
-    int shape, qw, nqb, nseg, seg_len, nq_pad;
+    int shape, qw, nqb, nseg, nq_pad;
+    SegBounds segs;
     size_t bits_bytes;     // packed zero-target flags, at the start of the workspace
     size_t shared_bytes;   // one cross-segment bound word per (padded) query
     size_t partial_bytes;  // per-segment top-k lists
     size_t total_bytes;
 };
 
+// Makespan (in 32-row tiles) of dispatching, in order, nqb workgroups per segment onto `slots`
+// concurrently resident workgroups; every workgroup costs its segment's tiles + `ov` tiles of fixed
+// work (query load, list set-up, final flush and write-out).
+static double simulate_makespan(const std::vector<int> &seg_tiles, int nqb, int slots, double ov) {
+    std::vector<double> heap((size_t)slots, 0.0);  // min-heap of slot free times
+    auto cmp = [](double a, double b) { return a > b; };
+    double last = 0.0;
+    for (int t : seg_tiles)
+        for (int q = 0; q < nqb; ++q) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            const double done = heap.back() + (double)t + ov;
+            heap.back() = done;
+            std::push_heap(heap.begin(), heap.end(), cmp);
+            last = std::max(last, done);
+        }
+    return last;
+}
+
+static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k);
+
+// the plan search simulates a few hundred dispatch orders: remember the last few results
+struct PlanCacheEntry {
+    int64_t nq, nt;
+    int dp, k, cus;
+    KnnPlan plan;
+};
+static thread_local std::vector<PlanCacheEntry> g_plan_cache;
+
 static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
+    const int dp = fdr_padded_dim(d);
+    for (const PlanCacheEntry &e : g_plan_cache)
+        if (e.nq == nq && e.nt == nt && e.dp == dp && e.k == k && e.cus == ctx->num_cus) return e.plan;
+    PlanCacheEntry e{nq, nt, dp, k, ctx->num_cus, knn_plan_compute(ctx, nq, nt, d, k)};
+    if (g_plan_cache.size() >= 16) g_plan_cache.erase(g_plan_cache.begin());
+    g_plan_cache.push_back(e);
+    if (const char *dbg = getenv("FDR_KNN_DEBUG")) {
+        if (atoi(dbg) & 8) {
+            fprintf(stderr, "[fdr plan] nq=%lld nt=%lld shape=%d nqb=%d nseg=%d tiles:", (long long)nq,
+                    (long long)nt, e.plan.shape, e.plan.nqb, e.plan.nseg);
+            for (int i = 0; i < e.plan.nseg; ++i)
+                fprintf(stderr, " %d", (e.plan.segs.b[i + 1] - e.plan.segs.b[i]) / 32);
+            fprintf(stderr, "\n");
+        }
+    }
+    return e.plan;
+}
+
+static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
     KnnPlan p;
     p.shape = knn_choose_shape(fdr_padded_dim(d), k);
     const KnnShape &sh = kShapes[p.shape];
     p.qw = 32 * sh.nq * sh.nw;
     p.nqb = (int)((nq + p.qw - 1) / p.qw);
     p.nq_pad = p.nqb * p.qw;
-    // Split the targets into nseg segments so that the grid (nqb x nseg workgroups of equal cost)
-    // fills the chip's workgroup slots in whole "rounds": pick the nseg with the best fill
-    // efficiency, charging ~1.5 % per extra segment for the top-k warm-up each segment repeats.
-    const long long slots = (long long)ctx->num_cus * std::max(1, knn_wg_per_cu(sh, k));
-    const long long max_seg = std::max<long long>(1, std::min<long long>(nt / 2048, 24));
-    long long nseg = 1;
-    double best_score = -1.0;
-    for (long long c = 1; c <= max_seg; ++c) {
-        const double rounds = (double)p.nqb * c / (double)slots;
-        const double eff = rounds / std::ceil(rounds);
-        const double score = eff - 0.015 * (double)(c - 1);
-        if (score > best_score + 1e-9) {
-            best_score = score;
-            nseg = c;
+    // Work split.  The grid is nqb query blocks x nseg target segments; workgroups are dispatched
+    // segment by segment onto `slots` resident workgroups.  Equal segments leave the last "round"
+    // mostly empty whenever nqb * nseg is not just below a multiple of `slots`, so the plan is a few
+    // long segments followed by shorter ones that fill the tail (guided self-scheduling), chosen by
+    // simulating the dispatch.  Segments of one query block share their bound (topk_share), so the
+    // extra segments cost little more than their fixed set-up (`ov`, in tiles).
+    const int slots = ctx->num_cus * std::max(1, knn_wg_per_cu(sh, k));
+    const int T = (int)((nt + 31) / 32);  // tiles
+    double ov = 16.0;
+    if (const char *e = getenv("FDR_KNN_OV")) ov = atof(e);  // development knob
+    std::vector<int> best{T};
+    double best_cost = simulate_makespan(best, p.nqb, slots, ov);
+    const int min_tiles = 24;  // never cut segments shorter than 768 rows
+    for (int cmain = 1; cmain <= 24; ++cmain)
+        for (int tf = 0; tf <= 4; ++tf)          // share of the tiles given to the short tail
+            for (int div = 2; div <= 8; div *= 2) {  // tail segments are 1/div of a main segment
+                const double tail_frac = 0.08 * tf;
+                if (tf == 0 && div != 2) continue;
+                const int main_total = (int)((1.0 - tail_frac) * T);
+                const int lm = std::max(min_tiles, (main_total + cmain - 1) / cmain);
+                std::vector<int> segs;
+                int left = T;
+                for (int i = 0; i < cmain && left > 0; ++i) {
+                    const int t = std::min(left, lm);
+                    segs.push_back(t);
+                    left -= t;
+                }
+                const int ls = std::max(min_tiles, lm / div);
+                while (left > 0) {
+                    const int t = (left < ls + min_tiles) ? left : ls;
+                    segs.push_back(t);
+                    left -= t;
+                }
+                if ((int)segs.size() > FDR_MAX_SEG) continue;
+                const double cost = simulate_makespan(segs, p.nqb, slots, ov);
+                if (cost < best_cost * 0.999) {
+                    best_cost = cost;
+                    best = segs;
+                }
+            }
+    if (const char *e = getenv("FDR_KNN_NSEG")) {  // development knob: nseg equal segments
+        const int c = std::max(1, std::min(atoi(e), FDR_MAX_SEG));
+        if (atoi(e) > 0) {
+            best.clear();
+            const int l = (T + c - 1) / c;
+            for (int left = T; left > 0; left -= l) best.push_back(std::min(left, l));
         }
     }
-    if (const char *e = getenv("FDR_KNN_NSEG")) {  // development knob
-        if (atoi(e) > 0) nseg = atoi(e);
+    p.nseg = (int)best.size();
+    int row = 0;
+    for (int i = 0; i < p.nseg; ++i) {
+        p.segs.b[i] = row;
+        row += best[(size_t)i] * 32;
     }
-    long long seg_len = (nt + nseg - 1) / nseg;
-    seg_len = (seg_len + 31) / 32 * 32;
-    nseg = (nt + seg_len - 1) / seg_len;
-    p.nseg = (int)nseg;
-    p.seg_len = (int)seg_len;
+    for (int i = p.nseg; i <= FDR_MAX_SEG; ++i) p.segs.b[i] = row;
     p.partial_bytes = (size_t)p.nseg * p.nq_pad * (size_t)k * sizeof(u64);
     p.bits_bytes = ((size_t)((nt + 31) / 32) * 4 + 255) / 256 * 256;
     p.shared_bytes = ((size_t)p.nq_pad * 4 + 255) / 256 * 256;
@@ -954,7 +1039,7 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<DP_, NQ_, NW_, WPS_>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
         hipLaunchKernelGGL((knn_tile_kernel<DP_, NQ_, NW_, WPS_>), grid, dim3(64 * NW_), lds, st, d_Qhat, \
-                           d_qzero, (int)nq, d_That, d_bits, (int)nt, (int)t_base, p.seg_len, k,     \
+                           d_qzero, (int)nq, d_That, d_bits, (int)nt, (int)t_base, p.segs, k,        \
                            p.nq_pad, d_partial, d_shared, dbg);                                      \
     } while (0)
     switch (p.shape) {
