@@ -546,21 +546,37 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
 // Keys are unique (each target lives in exactly one segment), so "smallest key greater than the
 // previous pick" enumerates them in order.
 // ------------------------------------------------------------------------------------------
+#define MERGE_CAP 512  // keys per query staged in LDS; longer candidate sets are re-read from global
+
 __global__ __launch_bounds__(256) void knn_merge_kernel(const u64 *__restrict__ partial, int nseg,
                                                         int nq, int nq_pad, int K,
                                                         int *__restrict__ idx_out,
                                                         float *__restrict__ dist_out) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ u64 stage[4][MERGE_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
     if (q >= nq) return;
     const int M = nseg * K;
+    const bool staged = M <= MERGE_CAP;
+    u64 *mine_lds = stage[wave];
+    if (staged) {  // one pass over global memory; the k selection rounds then run out of LDS
+        for (int m = lane; m < M; m += 64) {
+            const int seg = m / K, e = m - seg * K;
+            mine_lds[m] = partial[((size_t)seg * nq_pad + q) * K + e];
+        }
+    }
     u64 prev1 = 0;  // previous pick + 1 (0 = none yet)
     u64 mine = 0;
     for (int r = 0; r < K; ++r) {
         u64 best = ~0ull;
         for (int m = lane; m < M; m += 64) {
-            const int seg = m / K, e = m - seg * K;
-            const u64 kv = partial[((size_t)seg * nq_pad + q) * K + e];
+            u64 kv;
+            if (staged) {
+                kv = mine_lds[m];
+            } else {
+                const int seg = m / K, e = m - seg * K;
+                kv = partial[((size_t)seg * nq_pad + q) * K + e];
+            }
             if (kv + 1 > prev1 && kv < best) best = kv;
         }
 #pragma unroll
