@@ -53,19 +53,23 @@ static int fail(int code, const char *fmt, ...) {
 //
 // P (F x d) is "very sparse": >= 90 % of its feature rows are empty (density 1/sqrt(F)), so the
 // projection is stored as
-//   ftab[w]   = { bits: which of features 32w..32w+31 have a non-empty P row,
-//                 prefix: number of non-empty rows among features < 32w }           (8 B / 32 features)
-//   crow[r]   = offset of the r-th non-empty row's entries,   ent[q] = { column, fp32 bits }.
-// A wave streams its row's column ids 64 at a time (coalesced), tests the bitmap (L2 resident),
-// and only the few hits touch crow/ent.  Hits are applied in ascending feature order by the
-// whole wave (lane l owns columns l, l+64, ...), which reproduces scipy's sequential fp32 sums.
+//   ftab[w]    = { bits: which of features 32w..32w+31 have a non-empty P row,
+//                  prefix: number of non-empty rows among features < 32w }          (8 B / 32 features)
+//   rowinfo[r] = { start, count, first column, first value bits } of the r-th non-empty row  (16 B)
+//   ent[q]     = { column, fp32 bits }   (entries beyond a row's first)
+// A wave streams its row's column ids 256 at a time (four coalesced loads in flight), tests the
+// bitmap words (L2 resident) and fetches rowinfo for the hits, so a row pays the dependent
+// id -> bitmap -> rowinfo latency chain once per 256 non-zeros.  Hits are then applied in ascending
+// feature order by the whole wave (lane l owns columns l, l+64, ...), which reproduces scipy's
+// sequential fp32 sums bit for bit.
 // ------------------------------------------------------------------------------------------
 template <int DP>
 __global__ __launch_bounds__(256) void embed_csr_kernel(
     long long n_rows, const long long *__restrict__ a_indptr, const int *__restrict__ a_indices,
-    long long n_features, const uint2 *__restrict__ ftab, const int *__restrict__ crow,
+    long long n_features, const uint2 *__restrict__ ftab, const uint4 *__restrict__ rowinfo,
     const uint2 *__restrict__ ent, int d, float *__restrict__ E) {
     constexpr int NACC = DP / 64;
+    constexpr int NB = 4;  // 64-id chunks in flight per wave
     const int lane = threadIdx.x & 63;
     const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
@@ -74,41 +78,47 @@ __global__ __launch_bounds__(256) void embed_csr_kernel(
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
         const long long beg = a_indptr[row], end = a_indptr[row + 1];
-        for (long long base = beg; base < end; base += 64) {
-            const long long pos = base + lane;
-            int f = -1;
-            if (pos < end) f = a_indices[pos];
-            bool hit = false;
-            int s = 0, e = 0;
-            uint2 first = make_uint2(0u, 0u);
-            if (f >= 0 && (long long)f < n_features) {
-                const uint2 w = ftab[f >> 5];
-                const unsigned bit = 1u << (f & 31);
-                if (w.x & bit) {
-                    hit = true;
-                    const int r = (int)w.y + __popc(w.x & (bit - 1u));
-                    s = crow[r];
-                    e = crow[r + 1];
-                    first = ent[s];
-                }
-            }
-            u64 m = __ballot(hit);
-            while (m) {  // wave-uniform: hits in ascending lane = ascending feature order
-                const int src = __builtin_ctzll(m);
-                m &= m - 1;
-                const int ss = __builtin_amdgcn_readlane(s, src);
-                const int ee = __builtin_amdgcn_readlane(e, src);
-                unsigned c = (unsigned)__builtin_amdgcn_readlane((int)first.x, src);
-                float v = __int_as_float(__builtin_amdgcn_readlane((int)first.y, src));
-                int q = ss;
-                while (true) {
+        for (long long base = beg; base < end; base += 64 * NB) {
+            int f[NB];
 #pragma unroll
-                    for (int i = 0; i < NACC; ++i)
-                        if (c == (unsigned)(lane + 64 * i)) acc[i] += v;
-                    if (++q >= ee) break;
-                    const uint2 en = ent[q];  // same address in every lane
-                    c = en.x;
-                    v = __uint_as_float(en.y);
+            for (int u = 0; u < NB; ++u) {
+                const long long pos = base + 64 * u + lane;
+                f[u] = pos < end ? a_indices[pos] : -1;
+            }
+            uint2 w[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                w[u] = make_uint2(0u, 0u);
+                if (f[u] >= 0 && (long long)f[u] < n_features) w[u] = ftab[f[u] >> 5];
+            }
+            uint4 info[NB];
+            bool hit[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const unsigned bit = 1u << (f[u] & 31);
+                hit[u] = (w[u].x & bit) != 0u;
+                info[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (hit[u]) info[u] = rowinfo[w[u].y + __popc(w[u].x & (bit - 1u))];
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                u64 m = __ballot(hit[u]);
+                while (m) {  // wave-uniform: hits in ascending lane = ascending feature order
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    int q = __builtin_amdgcn_readlane((int)info[u].x, src);
+                    const int ee = q + __builtin_amdgcn_readlane((int)info[u].y, src);
+                    unsigned c = (unsigned)__builtin_amdgcn_readlane((int)info[u].z, src);
+                    float v = __int_as_float(__builtin_amdgcn_readlane((int)info[u].w, src));
+                    while (true) {
+#pragma unroll
+                        for (int i = 0; i < NACC; ++i)
+                            if (c == (unsigned)(lane + 64 * i)) acc[i] += v;
+                        if (++q >= ee) break;
+                        const uint2 en = ent[q];  // same address in every lane
+                        c = en.x;
+                        v = __uint_as_float(en.y);
+                    }
                 }
             }
         }
@@ -757,7 +767,7 @@ FDR_EXPORT int fdr_projection_load(fdr_ctx *ctx, int64_t n_features, int32_t d,
         return fail(FDR_E_ARG, "projection: bad CSR arrays");
     const int64_t nwords = (n_features + 31) / 32;
     std::vector<uint2> ftab((size_t)nwords);
-    std::vector<int> crow;
+    std::vector<uint4> crow;  // rowinfo
     std::vector<uint2> ent((size_t)std::max<int64_t>(nnz, 1));
     crow.reserve(1024);
     unsigned rows = 0;
@@ -770,7 +780,9 @@ FDR_EXPORT int fdr_projection_load(fdr_ctx *ctx, int64_t n_features, int32_t d,
             if (e < s || e > nnz) return fail(FDR_E_ARG, "projection: indptr not monotone at %lld", (long long)f);
             if (e > s) {
                 bits |= 1u << (unsigned)(f - f0);
-                crow.push_back((int)s);
+                uint32_t fv;
+                memcpy(&fv, &p_vals[s], 4);
+                crow.push_back(make_uint4((unsigned)s, (unsigned)(e - s), (unsigned)p_cols[s], fv));
                 ++rows;
                 for (int64_t q = s; q < e; ++q) {
                     if (p_cols[q] < 0 || p_cols[q] >= d)
@@ -784,12 +796,12 @@ FDR_EXPORT int fdr_projection_load(fdr_ctx *ctx, int64_t n_features, int32_t d,
         }
         ftab[(size_t)w] = make_uint2(bits, prefix);
     }
-    crow.push_back((int)nnz);
+    if (crow.empty()) crow.push_back(make_uint4(0u, 0u, 0u, 0u));
     if ((rc = ctx->ftab.reserve(ftab.size() * sizeof(uint2)))) return rc;
-    if ((rc = ctx->crow.reserve(crow.size() * sizeof(int)))) return rc;
+    if ((rc = ctx->crow.reserve(crow.size() * sizeof(uint4)))) return rc;
     if ((rc = ctx->ent.reserve(ent.size() * sizeof(uint2)))) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->ftab.p, ftab.data(), ftab.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->crow.p, crow.data(), crow.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->crow.p, crow.data(), crow.size() * sizeof(uint4), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->ent.p, ent.data(), ent.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->n_features = n_features;
@@ -813,7 +825,7 @@ static int launch_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *d_indptr,
 #define FDR_LAUNCH_EMBED(DP_)                                                                   \
     hipLaunchKernelGGL(embed_csr_kernel<DP_>, dim3(grid), dim3(256), 0, st, (long long)n_rows,  \
                        (const long long *)d_indptr, d_indices, ctx->n_features,                 \
-                       (const uint2 *)ctx->ftab.p, (const int *)ctx->crow.p,                    \
+                       (const uint2 *)ctx->ftab.p, (const uint4 *)ctx->crow.p,                  \
                        (const uint2 *)ctx->ent.p, ctx->d, d_E)
     if (dp == 128)
         FDR_LAUNCH_EMBED(128);
