@@ -15,9 +15,10 @@ SYMBOLS = (
     "fdr_create", "fdr_destroy", "fdr_last_error", "fdr_device_info", "fdr_padded_dim",
     "fdr_projection_load", "fdr_embed", "fdr_knn", "fdr_embed_knn", "fdr_embed_dev",
     "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_timing", "fdr_timing_read",
+    "fdr_last_uncertified",
 )
 FDR_MAX_K = 64
-KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge")
+KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank")
 FDR_MAX_DIM = 512
 
 
@@ -54,6 +55,7 @@ def load_library():
     L.fdr_knn_workspace_bytes.argtypes = [vp, i64, i64, i32, i32]
     L.fdr_knn_workspace_bytes.restype = sz
     L.fdr_knn_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, vp, sz, vp]
+    L.fdr_last_uncertified.argtypes = [vp]
     L.fdr_timing.argtypes = [vp, ctypes.c_int]
     L.fdr_timing_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(ctypes.c_float)]
@@ -126,6 +128,10 @@ class Context:
         if dp < 0:
             raise FedrannHipError("embedding dimension %d unsupported (1..%d)" % (d, FDR_MAX_DIM))
         return dp
+
+    def last_uncertified(self):
+        """Prefilter mode: query rows of the last k-NN call that were searched by the exact kernel."""
+        return int(self._L.fdr_last_uncertified(self._h))
 
     def timing(self, enable):
         self._check(self._L.fdr_timing(self._h, 1 if enable else 0), "fdr_timing")

@@ -604,6 +604,268 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const u64 *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Half-precision prefilter (optional mode, FDR_KNN_MODE=prefilter; d <= 128).
+//
+// P1 knn_prefilter_kernel: the same tiling and top-k machinery as K3, but the similarities come
+//    from v_mfma_f32_32x32x16_f16 on fp16 copies of the normalised rows (16x the fp32 MFMA rate)
+//    and the lists keep K' = K + 12 candidates per query, ordered by the APPROXIMATE distance.
+// P2 knn_rerank_kernel: per query, certifies that the K' candidates contain the exact top-K and, if
+//    so, recomputes their distances with the canonical fp32 fma chain and selects the K best by
+//    (dist, idx); otherwise the query is queued for the exact kernel (K3).
+//
+// Certificate.  Let eps bound |s~ - c| over all pairs (fp16 rounding of unit rows: 2*2^-11 relative
+// on sum |x||y| <= 1, plus subnormal and fp32 accumulation terms; FDR_PREFILTER_EPS), d~ the
+// approximate distances, d~(K) and d~(K') the K-th and K'-th smallest.  If
+//        d~(K) + M < 1   and   d~(K) + M < d~(K'),      M = 2*eps + 4e-7,
+// then every target outside the list has d~ >= d~(K') > d~(K) + M, hence an exact distance larger
+// than d~(K) + eps + 4e-7, while the K list members with the smallest d~ have exact distances
+// <= d~(K) + eps: nothing outside the list can reach the exact top-K, not even through an fp32
+// rounding tie (the 4e-7), and "< 1" keeps the argument inside the region where the distance is
+// strictly monotone in the similarity (no clamp plateau).  All-zero queries (d~ = 1 everywhere) and
+// heavy near-tie plateaus fail the test and take the exact path, so the final result is always the
+// canonical one.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define FDR_PREFILTER_EPS 0.00105f
+#define FDR_PREFILTER_EXTRA 12
+
+// Ehat fp32 [n, 128] (k0 k2 k4 k6 k1 k3 k5 k7 inside each group of 8) -> fp16 [n, 128], natural order
+__global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ Ehat, long long n,
+                                                      _Float16 *__restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;  // one thread per 8 components
+    if (t >= n * 16) return;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(Ehat) + t * 2;
+    const f32x4 e = src[0], o = src[1];  // even components k0 k2 k4 k6 | odd components k1 k3 k5 k7
+    f16x8 h;
+    h[0] = (_Float16)e.x; h[1] = (_Float16)o.x; h[2] = (_Float16)e.y; h[3] = (_Float16)o.y;
+    h[4] = (_Float16)e.z; h[5] = (_Float16)o.z; h[6] = (_Float16)e.w; h[7] = (_Float16)o.w;
+    reinterpret_cast<f16x8 *>(out)[t] = h;
+}
+
+// NW waves, one 32-query set per wave (QW = 32*NW queries per workgroup); a stage holds TPS tiles of
+// 32 target rows x 128 fp16 components (8 KB per tile).
+template <int NW, int TPS, int WPS>
+__global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
+    const _Float16 *__restrict__ Qh, int nq, const _Float16 *__restrict__ Th, int nt, int t_base,
+    SegBounds segs, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = 64 * NW;
+    constexpr int QW = 32 * NW;
+    constexpr int DP = 128;
+    constexpr int STAGE_BYTES = TPS * 32 * 256;
+    constexpr int SLOTS = 16;
+    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES);
+    u64 *queues = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES + (size_t)K * QW * 8);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int ql = wave * 32 + j;
+    const int qg = blockIdx.x * QW + ql;
+    const int qrow = qg < nq ? qg : nq - 1;
+    unsigned *shared = tau_shared + qg;
+
+    f16x8 b[8];  // B fragments: k-step s covers components 16s + 8h .. 16s + 8h + 7
+    {
+        const f16x8 *qp = reinterpret_cast<const f16x8 *>(Qh + (size_t)qrow * DP);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) b[s] = qp[2 * s + h];
+    }
+    for (int i = tid; i < K * QW; i += NT) lists[i] = KEY_INF;
+    TopkState st;
+    st.taukey = KEY_INF;
+    st.taupos = 0;
+    st.qcnt = 0;
+    st.tau = topk_share(shared, KEY_INF, h);
+    st.cfloor = sim_floor(st.tau);
+
+    const int t_begin = segs.b[blockIdx.y];
+    const int t_end = min(nt, segs.b[blockIdx.y + 1]);
+    const int ntiles = (t_end - t_begin + 31) >> 5;
+    const int nstages = (ntiles + TPS - 1) / TPS;
+
+    constexpr int NPIECE = 8 * TPS;
+    static_assert(NPIECE % NW == 0, "pieces must divide evenly among the waves");
+    auto issue_stage = [&](int it, int buf) {
+        const int trow0 = t_begin + it * 32 * TPS;
+#pragma unroll
+        for (int u = 0; u < NPIECE / NW; ++u) {
+            const int piece = wave + NW * u;
+            const int row = 4 * piece + (lane >> 4), pslot = lane & 15;
+            const int trow = min(trow0 + row, t_end - 1);
+            const _Float16 *src = Th + (size_t)trow * DP + (size_t)((pslot ^ (row & 15)) * 8);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)src,
+                (__attribute__((address_space(3))) void *)(smem + buf * STAGE_BYTES + piece * 1024), 16, 0, 0);
+        }
+    };
+    if (nstages > 0) issue_stage(0, 0);
+    __syncthreads();
+
+    for (int it = 0; it < nstages; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nstages) issue_stage(it + 1, buf ^ 1);
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) {
+            const int t = it * TPS + tt;
+            if (t < ntiles) {  // wave-uniform
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const f16x8 *sb =
+                    reinterpret_cast<const f16x8 *>(smem + buf * STAGE_BYTES) + (32 * tt + j) * SLOTS;
+                const int sw = j & 15;
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb[(2 * s + h) ^ sw], b[s], acc, 0, 0, 0);
+                float mx = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+                const int tile_row0 = t_begin + t * 32;
+                if (__any(mx > st.cfloor))
+                    topk_append<NT, QW>(acc, st, lists, queues, shared, ql, K, tid, h, t_base + tile_row0,
+                                        t_end - tile_row0, false);
+            }
+        }
+        if ((it & 15) == 15) {
+            st.tau = topk_share(shared, st.taukey, h);
+            st.cfloor = sim_floor(st.tau);
+        }
+        __syncthreads();
+    }
+    if (__any(st.qcnt > 0)) st = topk_flush<NT, QW>(st, lists, queues, shared, ql, K, tid, h, false);
+    __syncthreads();
+    {
+        u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * QW) * K;
+        const int total = QW * K;
+        for (int i = tid; i < total; i += NT) {
+            const int q = i / K, e = i % K;
+            out[i] = lists[e * QW + q];
+        }
+    }
+}
+
+// P1's merge: like knn_merge_kernel but writes the KP sorted keys themselves
+__global__ __launch_bounds__(256) void knn_merge_keys_kernel(const u64 *__restrict__ partial, int nseg,
+                                                             int nq, int nq_pad, int KP,
+                                                             u64 *__restrict__ cand) {
+    __shared__ u64 stage[4][MERGE_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= nq) return;
+    const int M = nseg * KP;
+    const bool staged = M <= MERGE_CAP;
+    u64 *mine_lds = stage[wave];
+    if (staged)
+        for (int m = lane; m < M; m += 64) {
+            const int seg = m / KP, e = m - seg * KP;
+            mine_lds[m] = partial[((size_t)seg * nq_pad + q) * KP + e];
+        }
+    u64 prev1 = 0, mine = KEY_INF;
+    for (int r = 0; r < KP; ++r) {
+        u64 best = ~0ull;
+        for (int m = lane; m < M; m += 64) {
+            u64 kv;
+            if (staged) {
+                kv = mine_lds[m];
+            } else {
+                const int seg = m / KP, e = m - seg * KP;
+                kv = partial[((size_t)seg * nq_pad + q) * KP + e];
+            }
+            if (kv + 1 > prev1 && kv < best) best = kv;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const u64 o = __shfl_xor(best, off);
+            best = o < best ? o : best;
+        }
+        // several KEY_INF entries (lists that never filled) are not unique: stop advancing there
+        if (best >= KEY_INF) best = KEY_INF; else prev1 = best + 1;
+        if (lane == r) mine = best;
+    }
+    if (lane < KP) cand[(size_t)q * KP + lane] = mine;
+}
+
+// P2: certificate + exact re-rank.  One wave per query, one lane per candidate.
+__global__ __launch_bounds__(256) void knn_rerank_kernel(
+    const u64 *__restrict__ cand, int KP, int K, const float *__restrict__ Qhat,
+    const float *__restrict__ That, int nq, int DP, int t_base, float margin,
+    int *__restrict__ idx_out, float *__restrict__ dist_out, int *__restrict__ counter,
+    int *__restrict__ flagged) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    u64 key = KEY_INF;
+    if (lane < KP) key = cand[(size_t)q * KP + lane];
+    const float dt = __uint_as_float((unsigned)(key >> 32));
+    const float dK = __shfl(dt, K - 1), dKP = __shfl(dt, KP - 1);
+    const bool valid = (dK + margin < 1.0f) && (dK + margin < dKP);
+    if (!valid) {
+        if (lane == 0) flagged[atomicAdd(counter, 1)] = q;
+        return;
+    }
+    u64 exact = ~0ull;
+    if (lane < KP && key < KEY_INF) {
+        const int tidx = (int)(unsigned)(key & 0xffffffffull);
+        const f32x4 *qp = reinterpret_cast<const f32x4 *>(Qhat + (size_t)q * DP);
+        const f32x4 *tp = reinterpret_cast<const f32x4 *>(That + (size_t)(tidx - t_base) * DP);
+        float c = 0.0f;
+        for (int g = 0; g < DP / 8; ++g) {  // canonical chain: components 8g .. 8g+7 in ascending order
+            const f32x4 qe = qp[2 * g], qo = qp[2 * g + 1], te = tp[2 * g], to = tp[2 * g + 1];
+            c = __builtin_fmaf(qe.x, te.x, c);
+            c = __builtin_fmaf(qo.x, to.x, c);
+            c = __builtin_fmaf(qe.y, te.y, c);
+            c = __builtin_fmaf(qo.y, to.y, c);
+            c = __builtin_fmaf(qe.z, te.z, c);
+            c = __builtin_fmaf(qo.z, to.z, c);
+            c = __builtin_fmaf(qe.w, te.w, c);
+            c = __builtin_fmaf(qo.w, to.w, c);
+        }
+        exact = ((u64)__float_as_uint(dist_from_sim(c)) << 32) | (unsigned)tidx;
+    }
+    u64 prev1 = 0, mine = 0;
+    for (int r = 0; r < K; ++r) {
+        u64 best = (exact + 1 > prev1) ? exact : ~0ull;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const u64 o = __shfl_xor(best, off);
+            best = o < best ? o : best;
+        }
+        prev1 = best + 1;
+        if (lane == r) mine = best;
+    }
+    if (lane < K) {
+        idx_out[(size_t)q * K + lane] = (int)(unsigned)(mine & 0xffffffffull);
+        dist_out[(size_t)q * K + lane] = __uint_as_float((unsigned)(mine >> 32));
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_queries_kernel(const float *__restrict__ Qhat,
+                                                             const unsigned char *__restrict__ qzero,
+                                                             const int *__restrict__ list, int first,
+                                                             int count, int DP, float *__restrict__ Qc,
+                                                             unsigned char *__restrict__ qzc) {
+    const int i = blockIdx.x;  // one block per flagged query
+    if (i >= count) return;
+    const int q = list[first + i];
+    for (int c = threadIdx.x; c < DP; c += 256) Qc[(size_t)i * DP + c] = Qhat[(size_t)q * DP + c];
+    if (threadIdx.x == 0) qzc[i] = qzero[q];
+}
+
+__global__ __launch_bounds__(256) void scatter_results_kernel(const int *__restrict__ idxc,
+                                                              const float *__restrict__ distc,
+                                                              const int *__restrict__ list, int first,
+                                                              int count, int K, int *__restrict__ idx_out,
+                                                              float *__restrict__ dist_out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= count * K) return;
+    const int i = t / K, e = t - i * K;
+    const int q = list[first + i];
+    idx_out[(size_t)q * K + e] = idxc[t];
+    dist_out[(size_t)q * K + e] = distc[t];
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -643,9 +905,10 @@ struct fdr_ctx {
     DevBuf a_indptr, a_indices, E, Ehat, zero, idx, dist, ws;
     // timing: when enabled, every launch of kernel kind i gets its own hipEvent pair on the launch
     // stream; fdr_timing_read() sums the elapsed times of all launches since the last read
+    int last_flagged = 0;  // prefilter mode: queries of the last call that took the exact path
     bool timing = false;
     std::vector<hipEvent_t> ev_pool[FDR_NUM_KERNELS];  // start, stop, start, stop, ...
-    size_t ev_used[FDR_NUM_KERNELS] = {0, 0, 0, 0};
+    size_t ev_used[FDR_NUM_KERNELS] = {0, 0, 0, 0, 0, 0};
 };
 
 static int timing_begin(fdr_ctx *ctx, int kind, hipStream_t st) {
@@ -724,6 +987,8 @@ FDR_EXPORT int fdr_device_info(fdr_ctx *ctx, char *buf, int buflen) {
              ctx->prop.multiProcessorCount, (size_t)ctx->prop.totalGlobalMem);
     return FDR_OK;
 }
+
+FDR_EXPORT int fdr_last_uncertified(fdr_ctx *ctx) { return ctx ? ctx->last_flagged : 0; }
 
 FDR_EXPORT int fdr_timing(fdr_ctx *ctx, int enable) {
     if (!ctx) return fail(FDR_E_ARG, "null context");
@@ -866,18 +1131,22 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
 // register-limited).  Shape choice: see knn_choose_shape().
 struct KnnShape {
     int dp, nq, nw, wps;
+    int tps;  // > 0: fp16 prefilter shape with tps 32-row tiles per LDS stage
 };
 static const KnnShape kShapes[] = {
-    {128, 1, 4, 3},  // 128 queries/WG, <=168 VGPRs, up to 3 WG/CU
-    {128, 1, 8, 4},  // 256 queries/WG, <=128 VGPRs, up to 2 WG/CU
-    {128, 2, 4, 2},  // 256 queries/WG, <=256 VGPRs, up to 2 WG/CU
-    {256, 1, 8, 2},  // 256 queries/WG, <=256 VGPRs, 1 WG/CU
-    {512, 1, 4, 1},  // 128 queries/WG, one wave per SIMD: 512 registers per lane (256 of them queries)
+    {128, 1, 4, 3, 0},  // 128 queries/WG, <=168 VGPRs, up to 3 WG/CU
+    {128, 1, 8, 4, 0},  // 256 queries/WG, <=128 VGPRs, up to 2 WG/CU
+    {128, 2, 4, 2, 0},  // 256 queries/WG, <=256 VGPRs, up to 2 WG/CU
+    {256, 1, 8, 2, 0},  // 256 queries/WG, <=256 VGPRs, 1 WG/CU
+    {512, 1, 4, 1, 0},  // 128 queries/WG, one wave per SIMD: 512 registers per lane (256 of them queries)
+    {128, 1, 4, 3, 2},  // fp16 prefilter: 128 queries/WG, two tiles per stage
 };
+#define FDR_SHAPE_PREFILTER 5
 
 static size_t knn_lds_bytes(const KnnShape &sh, int k) {
     const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
-    return (size_t)2 * 32 * 64 * 4 + (size_t)k * qw * 8 + (size_t)QCAP * sh.nq * nt * 8;
+    const size_t stage = sh.tps > 0 ? (size_t)sh.tps * 32 * 256 : (size_t)32 * 64 * 4;
+    return 2 * stage + (size_t)k * qw * 8 + (size_t)QCAP * sh.nq * nt * 8;
 }
 
 static int knn_wg_per_cu(const KnnShape &sh, int k) {
@@ -928,21 +1197,22 @@ static double simulate_makespan(const std::vector<int> &seg_tiles, int nqb, int 
     return last;
 }
 
-static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k);
+static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k, int shape);
 
 // the plan search simulates a few hundred dispatch orders: remember the last few results
 struct PlanCacheEntry {
     int64_t nq, nt;
-    int dp, k, cus;
+    int dp, k, cus, shape;
     KnnPlan plan;
 };
 static thread_local std::vector<PlanCacheEntry> g_plan_cache;
 
-static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
+static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k, int shape = -1) {
     const int dp = fdr_padded_dim(d);
     for (const PlanCacheEntry &e : g_plan_cache)
-        if (e.nq == nq && e.nt == nt && e.dp == dp && e.k == k && e.cus == ctx->num_cus) return e.plan;
-    PlanCacheEntry e{nq, nt, dp, k, ctx->num_cus, knn_plan_compute(ctx, nq, nt, d, k)};
+        if (e.nq == nq && e.nt == nt && e.dp == dp && e.k == k && e.cus == ctx->num_cus && e.shape == shape)
+            return e.plan;
+    PlanCacheEntry e{nq, nt, dp, k, ctx->num_cus, shape, knn_plan_compute(ctx, nq, nt, d, k, shape)};
     if (g_plan_cache.size() >= 16) g_plan_cache.erase(g_plan_cache.begin());
     g_plan_cache.push_back(e);
     if (const char *dbg = getenv("FDR_KNN_DEBUG")) {
@@ -957,9 +1227,9 @@ static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k
     return e.plan;
 }
 
-static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
+static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k, int shape) {
     KnnPlan p;
-    p.shape = knn_choose_shape(fdr_padded_dim(d), k);
+    p.shape = shape >= 0 ? shape : knn_choose_shape(fdr_padded_dim(d), k);
     const KnnShape &sh = kShapes[p.shape];
     p.qw = 32 * sh.nq * sh.nw;
     p.nqb = (int)((nq + p.qw - 1) / p.qw);
@@ -972,11 +1242,11 @@ static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int 
     // extra segments cost little more than their fixed set-up (`ov`, in tiles).
     const int slots = ctx->num_cus * std::max(1, knn_wg_per_cu(sh, k));
     const int T = (int)((nt + 31) / 32);  // tiles
-    double ov = 16.0;
+    double ov = sh.tps > 0 ? 96.0 : 16.0;  // fp16 tiles are 16x shorter: the fixed cost weighs more
     if (const char *e = getenv("FDR_KNN_OV")) ov = atof(e);  // development knob
     std::vector<int> best{T};
     double best_cost = simulate_makespan(best, p.nqb, slots, ov);
-    const int min_tiles = 24;  // never cut segments shorter than 768 rows
+    const int min_tiles = sh.tps > 0 ? 128 : 24;  // never cut segments shorter than 768 (4096) rows
     for (int cmain = 1; cmain <= 24; ++cmain)
         for (int tf = 0; tf <= 4; ++tf)          // share of the tiles given to the short tail
             for (int div = 2; div <= 8; div *= 2) {  // tail segments are 1/div of a main segment
@@ -1026,13 +1296,54 @@ static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int 
     return p;
 }
 
+// ---- prefilter mode: workspace layout -------------------------------------------------------
+static bool knn_prefilter_wanted(int dp, int64_t nt, int k) {
+    const char *e = getenv("FDR_KNN_MODE");
+    if (!e || strcmp(e, "prefilter") != 0) return false;
+    const int kp = (k + FDR_PREFILTER_EXTRA + 1) & ~1;
+    return dp == 128 && kp <= FDR_MAX_K && nt >= kp;
+}
+
+struct PrefilterLayout {
+    int kp, chunk;
+    size_t knn_bytes;  // region shared (in stream order) by the prefilter pass and the exact passes
+    size_t off_ht, off_hq, off_cand, off_counter, off_flagged, off_qc, off_qzc, off_idxc, off_distc, total;
+};
+
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
+    PrefilterLayout L;
+    L.kp = (k + FDR_PREFILTER_EXTRA + 1) & ~1;
+    L.chunk = (int)std::min<int64_t>(nq, 16384);
+    const size_t exact_all = knn_plan(ctx, nq, nt, d, k).total_bytes;
+    const size_t pre = knn_plan(ctx, nq, nt, d, L.kp, FDR_SHAPE_PREFILTER).total_bytes;
+    // any exact plan for <= chunk queries: bits + bound words + at most FDR_MAX_SEG segments of lists
+    const size_t chunk_bound = align256((size_t)((nt + 31) / 32) * 4) + align256((size_t)(L.chunk + 128) * 4) +
+                               (size_t)FDR_MAX_SEG * (L.chunk + 128) * (size_t)k * 8;
+    L.knn_bytes = align256(std::max(exact_all, std::max(pre, chunk_bound)));
+    size_t o = L.knn_bytes;
+    L.off_ht = o;       o += align256((size_t)nt * 128 * 2);
+    L.off_hq = o;       o += align256((size_t)nq * 128 * 2);
+    L.off_cand = o;     o += align256((size_t)nq * L.kp * 8);
+    L.off_counter = o;  o += 256;
+    L.off_flagged = o;  o += align256((size_t)nq * 4);
+    L.off_qc = o;       o += align256((size_t)L.chunk * 128 * 4);
+    L.off_qzc = o;      o += align256((size_t)L.chunk);
+    L.off_idxc = o;     o += align256((size_t)L.chunk * k * 4);
+    L.off_distc = o;    o += align256((size_t)L.chunk * k * 4);
+    L.total = o;
+    return L;
+}
+
 FDR_EXPORT size_t fdr_knn_workspace_bytes(fdr_ctx *ctx, int64_t nq, int64_t nt, int32_t d,
                                           int32_t k) {
     if (!ctx || nq <= 0 || nt <= 0 || k <= 0 || k > FDR_MAX_K || fdr_padded_dim(d) < 0) return 0;
+    if (knn_prefilter_wanted(fdr_padded_dim(d), nt, k)) return prefilter_layout(ctx, nq, nt, d, k).total;
     return knn_plan(ctx, nq, nt, d, k).total_bytes;
 }
 
-static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
+static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
                       const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base,
                       int d, int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes,
                       hipStream_t st) {
@@ -1096,6 +1407,101 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
                        (const u64 *)d_partial, p.nseg, (int)nq, p.nq_pad, k, d_idx, d_dist);
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_KNN_MERGE, st);
+}
+
+// ---- prefilter mode: fp16 pass -> certificate + exact re-rank -> exact pass for the rest -------
+static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
+                                const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base,
+                                int d, int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes,
+                                hipStream_t st) {
+    const PrefilterLayout L = prefilter_layout(ctx, nq, nt, d, k);
+    if (ws_bytes < L.total)
+        return fail(FDR_E_ARG, "knn: workspace %zu < required %zu bytes", ws_bytes, L.total);
+    char *ws = static_cast<char *>(d_ws);
+    _Float16 *d_ht = reinterpret_cast<_Float16 *>(ws + L.off_ht);
+    _Float16 *d_hq = reinterpret_cast<_Float16 *>(ws + L.off_hq);
+    u64 *d_cand = reinterpret_cast<u64 *>(ws + L.off_cand);
+    int *d_counter = reinterpret_cast<int *>(ws + L.off_counter);
+    int *d_flagged = reinterpret_cast<int *>(ws + L.off_flagged);
+    float *d_qc = reinterpret_cast<float *>(ws + L.off_qc);
+    uint8_t *d_qzc = reinterpret_cast<uint8_t *>(ws + L.off_qzc);
+    int32_t *d_idxc = reinterpret_cast<int32_t *>(ws + L.off_idxc);
+    float *d_distc = reinterpret_cast<float *>(ws + L.off_distc);
+    const int kp = L.kp;
+
+    const KnnPlan p = knn_plan(ctx, nq, nt, d, kp, FDR_SHAPE_PREFILTER);
+    const KnnShape &sh = kShapes[FDR_SHAPE_PREFILTER];
+    unsigned *d_bits = reinterpret_cast<unsigned *>(ws);
+    unsigned *d_shared = reinterpret_cast<unsigned *>(ws + p.bits_bytes);
+    u64 *d_partial = reinterpret_cast<u64 *>(ws + p.bits_bytes + p.shared_bytes);
+
+    int trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st);
+    if (trc) return trc;
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nt * 16 + 255) / 256)), dim3(256), 0, st, d_That,
+                       (long long)nt, d_ht);
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nq * 16 + 255) / 256)), dim3(256), 0, st, d_Qhat,
+                       (long long)nq, d_hq);
+    hipLaunchKernelGGL(pack_zero_bits_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st,
+                       d_tzero, (int)nt, d_bits, d_shared, p.nq_pad);
+    HIP_TRY(hipGetLastError());
+    const size_t lds = knn_lds_bytes(sh, kp);
+    if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn prefilter: k'=%d needs %zu B of LDS", kp, lds);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<4, 2, 3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((knn_prefilter_kernel<4, 2, 3>), dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(256),
+                       lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial,
+                       d_shared);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
+                       (const u64 *)d_partial, p.nseg, (int)nq, p.nq_pad, kp, d_cand);
+    HIP_TRY(hipGetLastError());
+    if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
+
+    if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
+    HIP_TRY(hipMemsetAsync(d_counter, 0, 4, st));
+    const float margin = 2.0f * FDR_PREFILTER_EPS + 4.0e-7f;
+    hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
+                       (const u64 *)d_cand, kp, k, d_Qhat, d_That, (int)nq, 128, (int)t_base, margin, d_idx,
+                       d_dist, d_counter, d_flagged);
+    HIP_TRY(hipGetLastError());
+    if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
+
+    // how many queries could not be certified?  (one 4-byte read-back; the exact passes below are
+    // sized from it)
+    int count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, d_counter, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    ctx->last_flagged = count;
+    if (count <= 0) return FDR_OK;
+    if ((int64_t)count * 2 > nq)  // the prefilter did not help on this input: one exact pass for everyone
+        return launch_knn_exact(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
+                                d_ws, L.knn_bytes, st);
+    for (int first = 0; first < count; first += L.chunk) {
+        const int c = std::min(L.chunk, count - first);
+        hipLaunchKernelGGL(gather_queries_kernel, dim3((unsigned)c), dim3(256), 0, st, d_Qhat, d_qzero,
+                           (const int *)d_flagged, first, c, 128, d_qc, d_qzc);
+        HIP_TRY(hipGetLastError());
+        int rc = launch_knn_exact(ctx, d_qc, d_qzc, c, d_That, d_tzero, nt, t_base, d, k, d_idxc, d_distc,
+                                  d_ws, L.knn_bytes, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(scatter_results_kernel, dim3((unsigned)(((int64_t)c * k + 255) / 256)), dim3(256),
+                           0, st, (const int *)d_idxc, (const float *)d_distc, (const int *)d_flagged, first,
+                           c, k, d_idx, d_dist);
+        HIP_TRY(hipGetLastError());
+    }
+    return FDR_OK;
+}
+
+static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
+                      const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int d,
+                      int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes, hipStream_t st) {
+    const int dp = fdr_padded_dim(d);
+    if (dp > 0 && k >= 1 && k <= FDR_MAX_K && nq > 0 && nt >= k && knn_prefilter_wanted(dp, nt, k) &&
+        d_Qhat && d_qzero && d_That && d_tzero && d_idx && d_dist && d_ws)
+        return launch_knn_prefilter(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx,
+                                    d_dist, d_ws, ws_bytes, st);
+    return launch_knn_exact(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
+                            d_ws, ws_bytes, st);
 }
 
 // ---- device-pointer API ----------------------------------------------------------------------

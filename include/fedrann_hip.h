@@ -109,9 +109,14 @@ int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64
 #define FDR_KERNEL_NORMALIZE 1
 #define FDR_KERNEL_KNN_TILE 2
 #define FDR_KERNEL_KNN_MERGE 3
-#define FDR_NUM_KERNELS 4
+#define FDR_KERNEL_KNN_PREFILTER 4 /* fp16 prefilter pass (FDR_KNN_MODE=prefilter), incl. conversion + merge */
+#define FDR_KERNEL_KNN_RERANK 5    /* certificate + exact fp32 re-rank of the prefilter's candidates */
+#define FDR_NUM_KERNELS 6
 int fdr_timing(fdr_ctx *ctx, int enable);
 int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out);
+/* Prefilter mode only: number of query rows of the most recent k-NN call whose candidate set could
+ * not be certified and that were therefore searched by the exact kernel. */
+int fdr_last_uncertified(fdr_ctx *ctx);
 
 #ifdef __cplusplus
 }

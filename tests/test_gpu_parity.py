@@ -12,6 +12,14 @@ from fedrann_amd.synth import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["exact", "prefilter"])
+def knn_mode(request, monkeypatch):
+    """Every test runs under both k-NN modes.  "prefilter" = fp16 MFMA candidate pass + certificate +
+    exact fp32 re-rank (exact kernel for uncertified queries); its results must be the same bits."""
+    monkeypatch.setenv("FDR_KNN_MODE", request.param)
+    return request.param
+
+
 def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
@@ -177,6 +185,29 @@ def test_knn_one_million_rows_sampled_oracle(ctx, oracle):
     Eh, _, zero = oracle.normalize(E)
     wi, wd = oracle.knn_normalized(Eh[rows], zero[rows], Eh, zero, 20)
     _assert_knn_equal((idx[rows], dist[rows]), (wi, wd))
+
+
+def test_prefilter_error_bound_and_fallback_accounting(ctx, oracle, knn_mode):
+    """The certificate's eps must bound |fp16 similarity - fp32 chain| (checked on sampled pairs with
+    numpy's fp16), and an input made of near-ties must be routed through the exact kernel."""
+    if knn_mode != "prefilter":
+        pytest.skip("prefilter mode only")
+    rng = np.random.default_rng(12)
+    E = rng.standard_normal((4000, 128)).astype(np.float32)
+    E[rng.random(E.shape) < 0.9] = 0  # sparse rows like the real embeddings
+    E[np.abs(E).sum(1) == 0, 0] = 1
+    Eh, _, _ = oracle.normalize(E)
+    a, b = rng.integers(0, 4000, size=20000), rng.integers(0, 4000, size=20000)
+    exact = np.array([oracle.pair_dist(Eh[i], Eh[j]) for i, j in zip(a[:2000], b[:2000])], np.float32)
+    h = Eh.astype(np.float16).astype(np.float64)
+    approx = 1.0 - (h[a[:2000]] * h[b[:2000]]).sum(1)
+    assert np.abs(np.clip(approx, 0, 1) - exact).max() < 0.00105
+    _assert_knn_equal(ctx.knn(E, 20), oracle.knn(E, 20))
+    # 3000 copies of 4 directions + noise at the 1e-4 level: every top-20 boundary is a near-tie
+    base = rng.standard_normal((4, 128)).astype(np.float32)
+    T = base[rng.integers(0, 4, size=3000)] + 1e-4 * rng.standard_normal((3000, 128)).astype(np.float32)
+    _assert_knn_equal(ctx.knn(T, 20), oracle.knn(T, 20))
+    assert ctx.last_uncertified() > 0
 
 
 # ---- error behaviour -----------------------------------------------------------------------------
