@@ -346,6 +346,11 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
             todo |= ((r & 3) + 8 * (r >> 2) + 4 * h < nvalid) ? (1u << r) : 0u;
     }
     const int idxh = idx0 + 4 * h;
+    // First pass over a tile: "dist < tau" is exact, because every listed or queued key comes from an
+    // earlier tile (smaller index).  After a mid-tile flush the list may hold rows of THIS tile from
+    // the partner lane, whose indices interleave with mine, so a retried candidate with dist == tau
+    // can still win on the index: retries admit dist <= tau and the flush's full-key test decides.
+    bool retry = false;
 #pragma unroll 1
     while (true) {
         DBG_COUNT(1);
@@ -358,7 +363,7 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
                 float a = acc[r];
                 asm volatile("" : "+v"(a));
                 const float dist = dist_from_sim(a);
-                if (((todo >> r) & 1u) && dist < st.tau) {
+                if (((todo >> r) & 1u) && (dist < st.tau || (retry && dist == st.tau))) {
                     if (st.qcnt < QCAP) {
                         queue[st.qcnt * NT + tid] =
                             ((u64)__float_as_uint(dist) << 32) | (unsigned)(idxh + (r & 3) + 8 * (r >> 2));
@@ -372,6 +377,7 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
         if (!__any(ovf != 0u)) break;
         st = topk_flush<NT, QW>(st, lists, queue, shared, ql, K, tid, h, dbgc);
         todo = ovf;
+        retry = true;
     }
 }
 

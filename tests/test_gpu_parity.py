@@ -187,6 +187,19 @@ def test_knn_one_million_rows_sampled_oracle(ctx, oracle):
     _assert_knn_equal((idx[rows], dist[rows]), (wi, wd))
 
 
+def test_knn_tight_clusters_all_ties(ctx, oracle):
+    """Thousands of rows at distance exactly 0 from each other: every list boundary is an index tie,
+    and queues overflow in the middle of tiles (regression: a retried candidate with dist == tau and a
+    smaller index than a row the partner lane had just inserted was dropped)."""
+    rng = np.random.default_rng(21)
+    base = rng.standard_normal((4, 128)).astype(np.float32)
+    T = base[rng.integers(0, 4, size=3000)] + 1e-4 * rng.standard_normal((3000, 128)).astype(np.float32)
+    for k in (20, 50):
+        _assert_knn_equal(ctx.knn(T, k), oracle.knn(T, k))
+    D = np.repeat(base, 700, axis=0)  # exact duplicates
+    _assert_knn_equal(ctx.knn(D, 33), oracle.knn(D, 33))
+
+
 def test_prefilter_error_bound_and_fallback_accounting(ctx, oracle, knn_mode):
     """The certificate's eps must bound |fp16 similarity - fp32 chain| (checked on sampled pairs with
     numpy's fp16), and an input made of near-ties must be routed through the exact kernel."""
