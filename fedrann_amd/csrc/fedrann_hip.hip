@@ -648,9 +648,13 @@ __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ 
     reinterpret_cast<f16x8 *>(out)[t] = h;
 }
 
-// NW waves, one 32-query set per wave (QW = 32*NW queries per workgroup); a stage holds TPS tiles of
-// 32 target rows x 128 fp16 components (8 KB per tile).
-template <int NW, int TPS, int WPS>
+// NW waves, one 32-query set per wave (QW = 32*NW queries per workgroup).  A stage is one tile of
+// 32 target rows x 128 fp16 components (8 KB); the LDS ring holds NS stages and runs NS-1 stages
+// ahead of the MFMAs: an fp16 tile is consumed in 256 MFMA cycles, far less than the LDS-DMA
+// latency, so the ring depth (bytes in flight), not the MFMA rate, sets the pace.  The DMA is
+// retired with a counted s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would make
+// hipcc drain vmcnt(0) and serialise the ring).
+template <int NW, int NS, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const _Float16 *__restrict__ Qh, int nq, const _Float16 *__restrict__ Th, int nt, int t_base,
     SegBounds segs, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared) {
@@ -658,10 +662,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     constexpr int NT = 64 * NW;
     constexpr int QW = 32 * NW;
     constexpr int DP = 128;
-    constexpr int STAGE_BYTES = TPS * 32 * 256;
+    constexpr int STAGE_BYTES = 32 * 256;
     constexpr int SLOTS = 16;
-    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES);
-    u64 *queues = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES + (size_t)K * QW * 8);
+    u64 *lists = reinterpret_cast<u64 *>(smem + NS * STAGE_BYTES);
+    u64 *queues = reinterpret_cast<u64 *>(smem + NS * STAGE_BYTES + (size_t)K * QW * 8);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -684,60 +688,87 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     st.qcnt = 0;
     st.tau = topk_share(shared, KEY_INF, h);
     st.cfloor = sim_floor(st.tau);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of mine in flight before the ring starts
 
     const int t_begin = segs.b[blockIdx.y];
     const int t_end = min(nt, segs.b[blockIdx.y + 1]);
-    const int ntiles = (t_end - t_begin + 31) >> 5;
-    const int nstages = (ntiles + TPS - 1) / TPS;
+    const int nstages = (t_end - t_begin + 31) >> 5;  // one tile per stage
 
-    constexpr int NPIECE = 8 * TPS;
-    static_assert(NPIECE % NW == 0, "pieces must divide evenly among the waves");
-    auto issue_stage = [&](int it, int buf) {
-        const int trow0 = t_begin + it * 32 * TPS;
+    constexpr int PPW = 8 / NW;  // 1 KiB LDS-DMA pieces per wave per stage
+    static_assert(8 % NW == 0 && PPW >= 1 && PPW <= 2, "unsupported wave count");
+    auto issue_stage = [&](int it) {
+        const int trow0 = t_begin + it * 32;
+        unsigned char *dst = smem + (it % NS) * STAGE_BYTES;
 #pragma unroll
-        for (int u = 0; u < NPIECE / NW; ++u) {
+        for (int u = 0; u < PPW; ++u) {
             const int piece = wave + NW * u;
             const int row = 4 * piece + (lane >> 4), pslot = lane & 15;
             const int trow = min(trow0 + row, t_end - 1);
             const _Float16 *src = Th + (size_t)trow * DP + (size_t)((pslot ^ (row & 15)) * 8);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)src,
-                (__attribute__((address_space(3))) void *)(smem + buf * STAGE_BYTES + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + piece * 1024),
+                                             16, 0, 0);
         }
     };
-    if (nstages > 0) issue_stage(0, 0);
-    __syncthreads();
+    // wait until at most `stages_in_flight` newer stages of THIS wave are still outstanding
+    auto wait_ring = [&](int stages_in_flight) {
+        if (stages_in_flight >= 2) {
+            if constexpr (NS >= 4) {
+                if (stages_in_flight >= 3) {
+                    if constexpr (PPW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    return;
+                }
+            }
+            if constexpr (PPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else if (stages_in_flight == 1) {
+            if constexpr (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    auto ring_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    constexpr int AHEAD = NS - 1;
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (i < nstages) issue_stage(i);
+    wait_ring(min(AHEAD, nstages) - 1);  // stage 0 has landed
+    __syncthreads();                     // (drains everything once; also publishes the list set-up)
 
     for (int it = 0; it < nstages; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nstages) issue_stage(it + 1, buf ^ 1);
+        if (it + AHEAD < nstages) issue_stage(it + AHEAD);  // its buffer was read in iteration it-1
+        {
+            f32x16 acc;
 #pragma unroll
-        for (int tt = 0; tt < TPS; ++tt) {
-            const int t = it * TPS + tt;
-            if (t < ntiles) {  // wave-uniform
-                f32x16 acc;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const f16x8 *sb = reinterpret_cast<const f16x8 *>(smem + (it % NS) * STAGE_BYTES) + j * SLOTS;
+            const int sw = j & 15;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                const f16x8 *sb =
-                    reinterpret_cast<const f16x8 *>(smem + buf * STAGE_BYTES) + (32 * tt + j) * SLOTS;
-                const int sw = j & 15;
+            for (int s = 0; s < 8; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb[(2 * s + h) ^ sw], b[s], acc, 0, 0, 0);
+            float mx = acc[0];
 #pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb[(2 * s + h) ^ sw], b[s], acc, 0, 0, 0);
-                float mx = acc[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-                const int tile_row0 = t_begin + t * 32;
-                if (__any(mx > st.cfloor))
-                    topk_append<NT, QW>(acc, st, lists, queues, shared, ql, K, tid, h, t_base + tile_row0,
-                                        t_end - tile_row0, false);
-            }
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+            const int tile_row0 = t_begin + it * 32;
+            if (__any(mx > st.cfloor))
+                topk_append<NT, QW>(acc, st, lists, queues, shared, ql, K, tid, h, t_base + tile_row0,
+                                    t_end - tile_row0, false);
         }
-        if ((it & 15) == 15) {
+        if ((it & 31) == 31) {
             st.tau = topk_share(shared, st.taukey, h);
             st.cfloor = sim_floor(st.tau);
         }
-        __syncthreads();
+        // stage it+1 must be complete (all waves' pieces) before anyone reads it; stages it+2 ..
+        // it+AHEAD stay in flight
+        const int newer = min(it + AHEAD, nstages - 1) - (it + 1);
+        wait_ring(newer < 0 ? 0 : newer);
+        ring_barrier();
     }
     if (__any(st.qcnt > 0)) st = topk_flush<NT, QW>(st, lists, queues, shared, ql, K, tid, h, false);
     __syncthreads();
@@ -1137,7 +1168,7 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
 // register-limited).  Shape choice: see knn_choose_shape().
 struct KnnShape {
     int dp, nq, nw, wps;
-    int tps;  // > 0: fp16 prefilter shape with tps 32-row tiles per LDS stage
+    int tps;  // > 0: fp16 prefilter shape whose LDS ring holds tps one-tile (8 KB) stages
 };
 static const KnnShape kShapes[] = {
     {128, 1, 4, 3, 0},  // 128 queries/WG, <=168 VGPRs, up to 3 WG/CU
@@ -1145,14 +1176,14 @@ static const KnnShape kShapes[] = {
     {128, 2, 4, 2, 0},  // 256 queries/WG, <=256 VGPRs, up to 2 WG/CU
     {256, 1, 8, 2, 0},  // 256 queries/WG, <=256 VGPRs, 1 WG/CU
     {512, 1, 4, 1, 0},  // 128 queries/WG, one wave per SIMD: 512 registers per lane (256 of them queries)
-    {128, 1, 4, 3, 2},  // fp16 prefilter: 128 queries/WG, two tiles per stage
+    {128, 1, 4, 3, 4},  // fp16 prefilter: 128 queries/WG, LDS ring of 4 one-tile stages
 };
 #define FDR_SHAPE_PREFILTER 5
 
 static size_t knn_lds_bytes(const KnnShape &sh, int k) {
     const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
-    const size_t stage = sh.tps > 0 ? (size_t)sh.tps * 32 * 256 : (size_t)32 * 64 * 4;
-    return 2 * stage + (size_t)k * qw * 8 + (size_t)QCAP * sh.nq * nt * 8;
+    const size_t ring = sh.tps > 0 ? (size_t)sh.tps * 32 * 256 : (size_t)2 * 32 * 64 * 4;
+    return ring + (size_t)k * qw * 8 + (size_t)QCAP * sh.nq * nt * 8;
 }
 
 static int knn_wg_per_cu(const KnnShape &sh, int k) {
@@ -1452,9 +1483,9 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     HIP_TRY(hipGetLastError());
     const size_t lds = knn_lds_bytes(sh, kp);
     if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn prefilter: k'=%d needs %zu B of LDS", kp, lds);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<4, 2, 3>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<4, 4, 3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((knn_prefilter_kernel<4, 2, 3>), dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(256),
+    hipLaunchKernelGGL((knn_prefilter_kernel<4, 4, 3>), dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(256),
                        lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial,
                        d_shared);
     HIP_TRY(hipGetLastError());
