@@ -223,6 +223,27 @@ def test_prefilter_error_bound_and_fallback_accounting(ctx, oracle, knn_mode):
     assert ctx.last_uncertified() > 0
 
 
+def test_device_api_query_subset_like_a_rank(ctx, oracle):
+    """fdr_normalize_dev + fdr_knn_dev on torch-owned buffers with the queries a SLICE of the targets
+    (what one rank of the row-sharded pipeline does), incl. a ragged, non-32-aligned slice."""
+    import torch
+    from fedrann_amd.distributed import HipEngine
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(31)
+    E = rng.standard_normal((9000, 128)).astype(np.float32)
+    E[rng.random(E.shape) < 0.93] = 0  # sparse rows: ties and a few all-zero rows
+    eng = HipEngine(ctx, dev)
+    dE = torch.from_numpy(E).to(dev)
+    Ehat = torch.zeros((9000, 128), dtype=torch.float32, device=dev)
+    zero = torch.zeros((9000,), dtype=torch.uint8, device=dev)
+    eng.normalize(dE, Ehat, zero)
+    wi, wd = oracle.knn(E, 20)
+    for lo, hi in ((0, 9000), (4500, 6750), (8967, 9000), (1, 130)):
+        idx, dst = eng.knn(Ehat[lo:hi], zero[lo:hi], hi - lo, Ehat, zero, 9000, 128, 20)
+        torch.cuda.synchronize(dev)
+        _assert_knn_equal((idx.cpu().numpy(), dst.cpu().numpy()), (wi[lo:hi], wd[lo:hi]))
+
+
 # ---- error behaviour -----------------------------------------------------------------------------
 def test_errors_are_raised_not_swallowed(ctx):
     E = np.zeros((10, 16), np.float32)
