@@ -25,7 +25,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (same guide; never the 2:1-sparse figure)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -41,6 +42,11 @@ def parse_args():
     p.add_argument("--cpu-baseline-seconds", type=float, default=15.0,
                    help="target CPU time of the cpu_baseline sample (0 = skip)")
     p.add_argument("--doubling", action="store_true", help="fwd/rev row doubling (2 rows per read)")
+    p.add_argument("--mode", choices=["auto", "exact", "prefilter"], default="auto",
+                   help="k-NN mode of the timed run (same results in every mode); auto = the library's "
+                        "default: fp16 prefilter + certificate + exact re-rank when it applies")
+    p.add_argument("--no-compare", action="store_true",
+                   help="skip the extra (separately timed) pass in the other k-NN mode")
     return p.parse_args()
 
 
@@ -123,6 +129,7 @@ def main():
     P = build_precompute_matrix(s["counts"], d)
 
     ctx = _lib.Context(local_rank)
+    ctx.set_knn_mode(args.mode)
     ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], d)
     engine = HipEngine(ctx, device)
     pipe = ShardedPipeline(engine, n, d, k, rank=rank, world_size=world, device=device)
@@ -137,25 +144,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        out = pipe.step(d_ip, d_ix)
-    barrier()
-    ctx.timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = pipe.step(d_ip, d_ix)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = {}
-    for i, name in enumerate(_lib.KERNELS):
-        cnt, ms = ctx.timing_read(i)
-        kernel_ms[name] = ms / max(cnt, 1)
-    ctx.timing(False)
+    def timed_run(steps, warmup):
+        """W untimed + K timed steps; returns (seconds, per-kernel average ms, last result)."""
+        res = None
+        for _ in range(warmup):
+            res = pipe.step(d_ip, d_ix)
+        barrier()
+        ctx.timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = pipe.step(d_ip, d_ix)
+        barrier()
+        dt = time.perf_counter() - t0
+        kms, kcnt = {}, {}
+        for i, name in enumerate(_lib.KERNELS):
+            cnt, ms = ctx.timing_read(i)
+            kms[name] = ms / max(cnt, 1)
+            kcnt[name] = cnt / max(steps, 1)
+        ctx.timing(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, kms, kcnt, res
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, kernel_ms, kernel_cnt, out = timed_run(args.steps, args.warmup)
+    uncertified = ctx.last_uncertified()
+    used_prefilter = kernel_cnt["knn_prefilter"] > 0
+
+    # the same workload in the other mode, separately timed (never part of `value`)
+    other = None
+    if not args.no_compare and (used_prefilter or args.mode != "exact"):
+        other_mode = "exact" if used_prefilter else "prefilter"
+        ctx.set_knn_mode(other_mode)
+        o_elapsed, o_ms, o_cnt, o_out = timed_run(args.steps, min(args.warmup, 1))
+        same = bool(torch.equal(out[0], o_out[0])) and bool(torch.equal(out[1], o_out[1]))
+        if o_cnt["knn_prefilter"] > 0 or other_mode == "exact":
+            other = {"mode": other_mode, "value": n * k * args.steps / o_elapsed, "unit": "read-pairs/s",
+                     "ms_per_step": o_elapsed / args.steps * 1e3, "kernels_ms": o_ms,
+                     "identical_to_timed_run": same}
+        ctx.set_knn_mode(args.mode)
 
     # sanity on the last step's result (not timed): self is its own nearest neighbour
     idx = out[0][: min(nloc, 4096)].cpu().numpy()
@@ -173,8 +201,18 @@ def main():
         value = n * k * args.steps / elapsed
         # roofline of the dominant kernel: all ordered (query, target) pairs of this rank, 2*d flop each
         flops = 2.0 * nloc * n * d
-        knn_ms = kernel_ms["knn_tile"]
-        achieved = flops / (knn_ms * 1e-3) / 1e12 if knn_ms > 0 else 0.0
+
+        def mfma_roofline(kms, prefilter):
+            name, peak = ("knn_prefilter", MFMA_F16_PEAK_TFLOPS) if prefilter else ("knn_tile", MFMA_F32_PEAK_TFLOPS)
+            ms = kms[name]
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"kernel": ("knn_prefilter_kernel (fp16 MFMA 32x32x16)" if prefilter
+                               else "knn_tile_kernel<%d> (fp32 MFMA 32x32x2)" % ctx.padded_dim(d)),
+                    "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "flops_per_launch": flops, "avg_launch_ms": ms}
+
+        roof = mfma_roofline(kernel_ms, used_prefilter)
+        achieved, knn_ms = roof["achieved"], roof["avg_launch_ms"]
         nnz_loc = int(ix.size)
         embed_bytes = 4.0 * nnz_loc + 8.0 * nloc + 4.0 * nloc * d
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as the
@@ -184,13 +222,16 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r1_summary.json")) as f:
                 prof = json.load(f)
             if (R, d, k, world, args.doubling) == (100_000, 128, 20, 1, False):
-                traffic = prof["pmc_per_launch_avg"]["knn_tile_kernel"]["hbm_bytes_per_launch"]
+                kname = "knn_prefilter_kernel" if used_prefilter else "knn_tile_kernel"
+                traffic = prof["pmc_per_launch_avg"][kname]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         result = {
             "metric": "read-pairs/sec (overlap candidates)", "value": value, "unit": "read-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (canonical fp32 results; fp16 MFMA candidate prefilter + exact fp32 re-rank)"
+                     if used_prefilter else "f32",
             "data": "synthetic",
             "config": {"workload": "%d synthetic ONT reads (%d rows%s), %d-dim projection, k-NN=%d, "
                                    "row-sharded over %d GPU(s)" % (R, n, ", fwd/rev doubled" if args.doubling else "",
@@ -198,17 +239,19 @@ def main():
                        "reads": R, "rows": n, "dim": d, "knn": k, "n_features": int(s["n_features"]),
                        "nnz": int(s["indptr"][-1]), "parallelism": "rows/%d + all-gather" % world,
                        "zero_row_fraction_sample": zero_frac, "self_check": ok},
-            "roofline": {"kernel": "knn_tile_kernel<%d>" % ctx.padded_dim(d), "bound": "mfma",
-                         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": "profiles/r1_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                           "bytes per launch)" if traffic else None,
-                         "flops_per_launch": flops, "avg_launch_ms": knn_ms},
+            "roofline": dict(roof, traffic=traffic,
+                             traffic_source="profiles/r1_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                            "bytes per launch)" if traffic else None),
+            "knn_mode": "prefilter" if used_prefilter else "exact",
+            "uncertified_queries_last_step": uncertified if used_prefilter else None,
             "kernels_ms": kernel_ms,
             "embed_roofline": {"bound": "hbm", "achieved": embed_bytes / (kernel_ms["embed_csr"] * 1e-3) / 1e9
                                if kernel_ms["embed_csr"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "bytes_per_launch": embed_bytes},
         }
+        if other is not None:
+            other["roofline"] = mfma_roofline(other["kernels_ms"], other["mode"] == "prefilter")
+            result["other_mode"] = other
         if world == 1 and args.cpu_baseline_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(s, P, d, k, args.cpu_baseline_seconds)
         else:

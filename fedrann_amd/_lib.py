@@ -15,7 +15,7 @@ SYMBOLS = (
     "fdr_create", "fdr_destroy", "fdr_last_error", "fdr_device_info", "fdr_padded_dim",
     "fdr_projection_load", "fdr_embed", "fdr_knn", "fdr_embed_knn", "fdr_embed_dev",
     "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_timing", "fdr_timing_read",
-    "fdr_last_uncertified",
+    "fdr_last_uncertified", "fdr_set_knn_mode",
 )
 FDR_MAX_K = 64
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank")
@@ -56,6 +56,7 @@ def load_library():
     L.fdr_knn_workspace_bytes.restype = sz
     L.fdr_knn_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, vp, sz, vp]
     L.fdr_last_uncertified.argtypes = [vp]
+    L.fdr_set_knn_mode.argtypes = [vp, ctypes.c_int]
     L.fdr_timing.argtypes = [vp, ctypes.c_int]
     L.fdr_timing_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(ctypes.c_float)]
@@ -128,6 +129,11 @@ class Context:
         if dp < 0:
             raise FedrannHipError("embedding dimension %d unsupported (1..%d)" % (d, FDR_MAX_DIM))
         return dp
+
+    def set_knn_mode(self, mode):
+        """mode: "auto" (default), "exact" or "prefilter" -- same results, see include/fedrann_hip.h."""
+        code = {"auto": 0, "exact": 1, "prefilter": 2}[mode]
+        self._check(self._L.fdr_set_knn_mode(self._h, code), "fdr_set_knn_mode")
 
     def last_uncertified(self):
         """Prefilter mode: query rows of the last k-NN call that were searched by the exact kernel."""

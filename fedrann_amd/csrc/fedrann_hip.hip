@@ -945,6 +945,7 @@ struct fdr_ctx {
     DevBuf a_indptr, a_indices, E, Ehat, zero, idx, dist, ws;
     // timing: when enabled, every launch of kernel kind i gets its own hipEvent pair on the launch
     // stream; fdr_timing_read() sums the elapsed times of all launches since the last read
+    int knn_mode = FDR_MODE_AUTO;
     int last_flagged = 0;  // prefilter mode: queries of the last call that took the exact path
     bool timing = false;
     std::vector<hipEvent_t> ev_pool[FDR_NUM_KERNELS];  // start, stop, start, stop, ...
@@ -1029,6 +1030,12 @@ FDR_EXPORT int fdr_device_info(fdr_ctx *ctx, char *buf, int buflen) {
 }
 
 FDR_EXPORT int fdr_last_uncertified(fdr_ctx *ctx) { return ctx ? ctx->last_flagged : 0; }
+
+FDR_EXPORT int fdr_set_knn_mode(fdr_ctx *ctx, int mode) {
+    if (!ctx || mode < FDR_MODE_AUTO || mode > FDR_MODE_PREFILTER) return fail(FDR_E_ARG, "bad k-NN mode");
+    ctx->knn_mode = mode;
+    return FDR_OK;
+}
 
 FDR_EXPORT int fdr_timing(fdr_ctx *ctx, int enable) {
     if (!ctx) return fail(FDR_E_ARG, "null context");
@@ -1337,11 +1344,19 @@ static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int 
 }
 
 // ---- prefilter mode: workspace layout -------------------------------------------------------
-static bool knn_prefilter_wanted(int dp, int64_t nt, int k) {
-    const char *e = getenv("FDR_KNN_MODE");
-    if (!e || strcmp(e, "prefilter") != 0) return false;
+// mode: FDR_MODE_AUTO uses the fp16 prefilter whenever it applies (d <= 128, k + 12 <= 64) and the
+// target set is large enough to pay for it; FDR_KNN_MODE=exact|prefilter|auto overrides the context.
+static bool knn_prefilter_wanted(const fdr_ctx *ctx, int dp, int64_t nt, int k) {
+    int mode = ctx->knn_mode;
+    if (const char *e = getenv("FDR_KNN_MODE")) {
+        if (strcmp(e, "exact") == 0) mode = FDR_MODE_EXACT;
+        else if (strcmp(e, "prefilter") == 0) mode = FDR_MODE_PREFILTER;
+        else if (strcmp(e, "auto") == 0) mode = FDR_MODE_AUTO;
+    }
+    if (mode == FDR_MODE_EXACT) return false;
     const int kp = (k + FDR_PREFILTER_EXTRA + 1) & ~1;
-    return dp == 128 && kp <= FDR_MAX_K && nt >= kp;
+    if (!(dp == 128 && kp <= FDR_MAX_K && nt >= kp)) return false;
+    return mode == FDR_MODE_PREFILTER || nt >= 8192;
 }
 
 struct PrefilterLayout {
@@ -1379,7 +1394,7 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
 FDR_EXPORT size_t fdr_knn_workspace_bytes(fdr_ctx *ctx, int64_t nq, int64_t nt, int32_t d,
                                           int32_t k) {
     if (!ctx || nq <= 0 || nt <= 0 || k <= 0 || k > FDR_MAX_K || fdr_padded_dim(d) < 0) return 0;
-    if (knn_prefilter_wanted(fdr_padded_dim(d), nt, k)) return prefilter_layout(ctx, nq, nt, d, k).total;
+    if (knn_prefilter_wanted(ctx, fdr_padded_dim(d), nt, k)) return prefilter_layout(ctx, nq, nt, d, k).total;
     return knn_plan(ctx, nq, nt, d, k).total_bytes;
 }
 
@@ -1475,7 +1490,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     unsigned *d_shared = reinterpret_cast<unsigned *>(ws + p.bits_bytes);
     u64 *d_partial = reinterpret_cast<u64 *>(ws + p.bits_bytes + p.shared_bytes);
 
-    int trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st);
+    int trc = timing_begin(ctx, FDR_KERNEL_KNN_RERANK, st);  // conversion + set-up count as "rerank"
     if (trc) return trc;
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nt * 16 + 255) / 256)), dim3(256), 0, st, d_That,
                        (long long)nt, d_ht);
@@ -1486,18 +1501,20 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     HIP_TRY(hipGetLastError());
     const size_t lds = knn_lds_bytes(sh, kp);
     if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn prefilter: k'=%d needs %zu B of LDS", kp, lds);
+    if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
+    if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<4, 4, 3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((knn_prefilter_kernel<4, 4, 3>), dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(256),
                        lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial,
                        d_shared, getenv("FDR_KNN_DEBUG") ? atoi(getenv("FDR_KNN_DEBUG")) : 0);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
-                       (const u64 *)d_partial, p.nseg, (int)nq, p.nq_pad, kp, d_cand);
-    HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
 
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
+    hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
+                       (const u64 *)d_partial, p.nseg, (int)nq, p.nq_pad, kp, d_cand);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(d_counter, 0, 4, st));
     const float margin = 2.0f * FDR_PREFILTER_EPS + 4.0e-7f;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
@@ -1536,7 +1553,7 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
                       const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int d,
                       int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes, hipStream_t st) {
     const int dp = fdr_padded_dim(d);
-    if (dp > 0 && k >= 1 && k <= FDR_MAX_K && nq > 0 && nt >= k && knn_prefilter_wanted(dp, nt, k) &&
+    if (dp > 0 && k >= 1 && k <= FDR_MAX_K && nq > 0 && nt >= k && knn_prefilter_wanted(ctx, dp, nt, k) &&
         d_Qhat && d_qzero && d_That && d_tzero && d_idx && d_dist && d_ws)
         return launch_knn_prefilter(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx,
                                     d_dist, d_ws, ws_bytes, st);

@@ -109,11 +109,24 @@ int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64
 #define FDR_KERNEL_NORMALIZE 1
 #define FDR_KERNEL_KNN_TILE 2
 #define FDR_KERNEL_KNN_MERGE 3
-#define FDR_KERNEL_KNN_PREFILTER 4 /* fp16 prefilter pass (FDR_KNN_MODE=prefilter), incl. conversion + merge */
-#define FDR_KERNEL_KNN_RERANK 5    /* certificate + exact fp32 re-rank of the prefilter's candidates */
+#define FDR_KERNEL_KNN_PREFILTER 4 /* fp16 MFMA candidate kernel of the prefilter mode */
+#define FDR_KERNEL_KNN_RERANK 5    /* rest of the prefilter mode: fp16 conversion, key merge, certificate +
+                                      exact fp32 re-rank (two timed spans per call) */
 #define FDR_NUM_KERNELS 6
 int fdr_timing(fdr_ctx *ctx, int enable);
 int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out);
+/* ---- k-NN mode ---------------------------------------------------------------------------------
+ * Both modes return the SAME canonical result.  EXACT: every pair through the
+ * fp32 MFMA kernel.  PREFILTER (d <= 128, k <= 52): an fp16 MFMA pass proposes k + 12 candidates per
+ * query; a certificate proves they contain the exact top-k and their distances are recomputed with
+ * the canonical fp32 chain; queries that cannot be certified are searched by the exact kernel.  The
+ * prefilter mode reads one 4-byte counter back per call (a stream synchronisation).  AUTO (default):
+ * PREFILTER when it applies and there are >= 8192 targets.  The environment variable
+ * FDR_KNN_MODE=exact|prefilter|auto overrides the context's setting. */
+#define FDR_MODE_AUTO 0
+#define FDR_MODE_EXACT 1
+#define FDR_MODE_PREFILTER 2
+int fdr_set_knn_mode(fdr_ctx *ctx, int mode);
 /* Prefilter mode only: number of query rows of the most recent k-NN call whose candidate set could
  * not be certified and that were therefore searched by the exact kernel. */
 int fdr_last_uncertified(fdr_ctx *ctx);
