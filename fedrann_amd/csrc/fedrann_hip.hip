@@ -635,6 +635,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FDR_PREFILTER_EPS 0.00105f
 #define FDR_PREFILTER_EXTRA 12
 
+static int prefilter_extra() {  // candidates kept beyond k (development knob FDR_KNN_EXTRA)
+    if (const char *e = getenv("FDR_KNN_EXTRA")) {
+        const int v = atoi(e);
+        if (v >= 2 && v <= 44) return v;
+    }
+    return FDR_PREFILTER_EXTRA;
+}
+
 // Ehat fp32 [n, 128] (k0 k2 k4 k6 k1 k3 k5 k7 inside each group of 8) -> fp16 [n, 128], natural order
 __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ Ehat, long long n,
                                                       _Float16 *__restrict__ out) {
@@ -1354,7 +1362,7 @@ static bool knn_prefilter_wanted(const fdr_ctx *ctx, int dp, int64_t nt, int k) 
         else if (strcmp(e, "auto") == 0) mode = FDR_MODE_AUTO;
     }
     if (mode == FDR_MODE_EXACT) return false;
-    const int kp = (k + FDR_PREFILTER_EXTRA + 1) & ~1;
+    const int kp = (k + prefilter_extra() + 1) & ~1;
     if (!(dp == 128 && kp <= FDR_MAX_K && nt >= kp)) return false;
     return mode == FDR_MODE_PREFILTER || nt >= 8192;
 }
@@ -1369,7 +1377,7 @@ static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
     PrefilterLayout L;
-    L.kp = (k + FDR_PREFILTER_EXTRA + 1) & ~1;
+    L.kp = (k + prefilter_extra() + 1) & ~1;
     L.chunk = (int)std::min<int64_t>(nq, 16384);
     const size_t exact_all = knn_plan(ctx, nq, nt, d, k).total_bytes;
     const size_t pre = knn_plan(ctx, nq, nt, d, L.kp, FDR_SHAPE_PREFILTER).total_bytes;
