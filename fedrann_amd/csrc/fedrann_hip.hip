@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const u64 *__restrict__ 
 //
 // P1 knn_prefilter_kernel: the same tiling and top-k machinery as K3, but the similarities come
 //    from v_mfma_f32_32x32x16_f16 on fp16 copies of the normalised rows (16x the fp32 MFMA rate)
-//    and the lists keep K' = K + 12 candidates per query, ordered by the APPROXIMATE distance.
+//    and the lists keep K' = K + 8 candidates per query, ordered by the APPROXIMATE distance.
 // P2 knn_rerank_kernel: per query, certifies that the K' candidates contain the exact top-K and, if
 //    so, recomputes their distances with the canonical fp32 fma chain and selects the K best by
 //    (dist, idx); otherwise the query is queued for the exact kernel (K3).
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const u64 *__restrict__ 
 // ------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FDR_PREFILTER_EPS 0.00105f
-#define FDR_PREFILTER_EXTRA 12
+#define FDR_PREFILTER_EXTRA 8
 
 static int prefilter_extra() {  // candidates kept beyond k (development knob FDR_KNN_EXTRA)
     if (const char *e = getenv("FDR_KNN_EXTRA")) {
@@ -656,13 +656,27 @@ __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ 
     reinterpret_cast<f16x8 *>(out)[t] = h;
 }
 
-// NW waves, one 32-query set per wave (QW = 32*NW queries per workgroup).  A stage is one tile of
-// 32 target rows x 128 fp16 components (8 KB); the LDS ring holds NS stages and runs NS-1 stages
-// ahead of the MFMAs: an fp16 tile is consumed in 256 MFMA cycles, far less than the LDS-DMA
-// latency, so the ring depth (bytes in flight), not the MFMA rate, sets the pace.  The DMA is
-// retired with a counted s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would make
-// hipcc drain vmcnt(0) and serialise the ring).
-template <int NW, int NS, int WPS>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) with a literal count
+    static_assert(N >= 0 && N <= 16, "count out of range");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "add the literal form for this count");
+}
+
+// NW waves, one 32-query set per wave (QW = 32*NW queries per workgroup).  A stage is TPS tiles of
+// 32 target rows x 128 fp16 components (8 KB each); the LDS ring holds NS stages and runs NS-1
+// stages ahead of the MFMAs: an fp16 tile is consumed in 256 MFMA cycles, far less than the LDS-DMA
+// latency.  The DMA is retired with a counted s_waitcnt vmcnt(N) and a raw s_barrier (a
+// __syncthreads() would make hipcc drain vmcnt(0) and serialise the ring).
+template <int NW, int NS, int TPS, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const _Float16 *__restrict__ Qh, int nq, const _Float16 *__restrict__ Th, int nt, int t_base,
     SegBounds segs, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared,
@@ -671,7 +685,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     constexpr int NT = 64 * NW;
     constexpr int QW = 32 * NW;
     constexpr int DP = 128;
-    constexpr int STAGE_BYTES = 32 * 256;
+    constexpr int STAGE_BYTES = TPS * 32 * 256;
     constexpr int SLOTS = 16;
     u64 *lists = reinterpret_cast<u64 *>(smem + NS * STAGE_BYTES);
     u64 *queues = reinterpret_cast<u64 *>(smem + NS * STAGE_BYTES + (size_t)K * QW * 8);
@@ -697,16 +711,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     st.qcnt = 0;
     st.tau = topk_share(shared, KEY_INF, h);
     st.cfloor = sim_floor(st.tau);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of mine in flight before the ring starts
+    wait_vmcnt<0>();  // nothing of mine in flight before the ring starts
 
     const int t_begin = segs.b[blockIdx.y];
     const int t_end = min(nt, segs.b[blockIdx.y + 1]);
-    const int nstages = (t_end - t_begin + 31) >> 5;  // one tile per stage
+    const int ntiles = (t_end - t_begin + 31) >> 5;
+    const int nstages = (ntiles + TPS - 1) / TPS;
 
-    constexpr int PPW = 8 / NW;  // 1 KiB LDS-DMA pieces per wave per stage
-    static_assert(8 % NW == 0 && PPW >= 1 && PPW <= 2, "unsupported wave count");
+    constexpr int PPW = 8 * TPS / NW;  // 1 KiB LDS-DMA pieces per wave per stage
+    static_assert((8 * TPS) % NW == 0 && PPW >= 1 && PPW <= 4, "unsupported geometry");
     auto issue_stage = [&](int it) {
-        const int trow0 = t_begin + it * 32;
+        const int trow0 = t_begin + it * 32 * TPS;
         unsigned char *dst = smem + (it % NS) * STAGE_BYTES;
 #pragma unroll
         for (int u = 0; u < PPW; ++u) {
@@ -719,24 +734,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
                                              16, 0, 0);
         }
     };
-    // wait until at most `stages_in_flight` newer stages of THIS wave are still outstanding
-    auto wait_ring = [&](int stages_in_flight) {
-        if (stages_in_flight >= 2) {
-            if constexpr (NS >= 4) {
-                if (stages_in_flight >= 3) {
-                    if constexpr (PPW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    return;
-                }
-            }
-            if constexpr (PPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else if (stages_in_flight == 1) {
-            if constexpr (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    // wait until at most `newer` later stages of THIS wave are still outstanding
+    auto wait_ring = [&](int newer) {
+        if (NS >= 4 && newer >= 3) wait_vmcnt<3 * PPW>();
+        else if (NS >= 3 && newer == 2) wait_vmcnt<2 * PPW>();
+        else if (newer == 1) wait_vmcnt<PPW>();
+        else wait_vmcnt<0>();
     };
     auto ring_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -752,26 +755,31 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
 
     for (int it = 0; it < nstages; ++it) {
         if (it + AHEAD < nstages) issue_stage(it + AHEAD);  // its buffer was read in iteration it-1
-        {
-            f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const f16x8 *sb = reinterpret_cast<const f16x8 *>(smem + (it % NS) * STAGE_BYTES) + j * SLOTS;
-            const int sw = j & 15;
+        for (int tt = 0; tt < TPS; ++tt) {
+            const int t = it * TPS + tt;
+            if (t < ntiles) {  // wave-uniform
+                f32x16 acc;
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb[(2 * s + h) ^ sw], b[s], acc, 0, 0, 0);
-            float mx = acc[0];
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const f16x8 *sb =
+                    reinterpret_cast<const f16x8 *>(smem + (it % NS) * STAGE_BYTES) + (32 * tt + j) * SLOTS;
+                const int sw = j & 15;
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-            const int tile_row0 = t_begin + it * 32;
-            if (dbg & 1) {  // timing experiment: MFMA + fast path only
-                if (mx > 3.0e38f) st.tau = mx;
-            } else if (__any(mx > st.cfloor))
-                topk_append<NT, QW>(acc, st, lists, queues, shared, ql, K, tid, h, t_base + tile_row0,
-                                    t_end - tile_row0, false);
+                for (int s = 0; s < 8; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb[(2 * s + h) ^ sw], b[s], acc, 0, 0, 0);
+                float mx = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+                const int tile_row0 = t_begin + t * 32;
+                if (dbg & 1) {  // timing experiment: MFMA + fast path only
+                    if (mx > 3.0e38f) st.tau = mx;
+                } else if (__any(mx > st.cfloor))
+                    topk_append<NT, QW>(acc, st, lists, queues, shared, ql, K, tid, h, t_base + tile_row0,
+                                        t_end - tile_row0, false);
+            }
         }
-        if ((it & 31) == 31) {
+        if ((it & 15) == 15) {
             st.tau = topk_share(shared, st.taukey, h);
             st.cfloor = sim_floor(st.tau);
         }
@@ -1352,7 +1360,7 @@ static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int 
 }
 
 // ---- prefilter mode: workspace layout -------------------------------------------------------
-// mode: FDR_MODE_AUTO uses the fp16 prefilter whenever it applies (d <= 128, k + 12 <= 64) and the
+// mode: FDR_MODE_AUTO uses the fp16 prefilter whenever it applies (d <= 128, k + 8 <= 64) and the
 // target set is large enough to pay for it; FDR_KNN_MODE=exact|prefilter|auto overrides the context.
 static bool knn_prefilter_wanted(const fdr_ctx *ctx, int dp, int64_t nt, int k) {
     int mode = ctx->knn_mode;
@@ -1511,11 +1519,21 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn prefilter: k'=%d needs %zu B of LDS", kp, lds);
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<4, 4, 3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((knn_prefilter_kernel<4, 4, 3>), dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(256),
-                       lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial,
-                       d_shared, getenv("FDR_KNN_DEBUG") ? atoi(getenv("FDR_KNN_DEBUG")) : 0);
+    const int pdbg = getenv("FDR_KNN_DEBUG") ? atoi(getenv("FDR_KNN_DEBUG")) : 0;
+    const int ring = getenv("FDR_KNN_RING") ? atoi(getenv("FDR_KNN_RING")) : 0;  // development knob
+#define FDR_LAUNCH_PRE(NS_, TPS_)                                                                       \
+    do {                                                                                                \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<4, NS_, TPS_, 3>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+        hipLaunchKernelGGL((knn_prefilter_kernel<4, NS_, TPS_, 3>), dim3((unsigned)p.nqb, (unsigned)p.nseg), \
+                           dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp,   \
+                           p.nq_pad, d_partial, d_shared, pdbg);                                        \
+    } while (0)
+    if (ring == 41) FDR_LAUNCH_PRE(4, 1);       // four one-tile stages
+    else if (ring == 31) { FDR_LAUNCH_PRE(3, 1); }  // (LDS is sized for 32 KB of ring in every variant)
+    else if (ring == 21) { FDR_LAUNCH_PRE(2, 1); }
+    else FDR_LAUNCH_PRE(2, 2);                  // two two-tile stages
+#undef FDR_LAUNCH_PRE
     HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
 
