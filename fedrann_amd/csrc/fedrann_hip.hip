@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const u64 *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Half-precision prefilter (optional mode, FDR_KNN_MODE=prefilter; d <= 128).
+// Half-precision prefilter (the default mode whenever k + 8 <= 64 and the lists fit in LDS).
 //
 // P1 knn_prefilter_kernel: the same tiling and top-k machinery as K3, but the similarities come
 //    from v_mfma_f32_32x32x16_f16 on fp16 copies of the normalised rows (16x the fp32 MFMA rate)
@@ -643,11 +643,11 @@ static int prefilter_extra() {  // candidates kept beyond k (development knob FD
     return FDR_PREFILTER_EXTRA;
 }
 
-// Ehat fp32 [n, 128] (k0 k2 k4 k6 k1 k3 k5 k7 inside each group of 8) -> fp16 [n, 128], natural order
-__global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ Ehat, long long n,
+// Ehat fp32 [n, DP] (k0 k2 k4 k6 k1 k3 k5 k7 inside each group of 8) -> fp16 [n, DP], natural order
+__global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ Ehat, long long n_groups,
                                                       _Float16 *__restrict__ out) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;  // one thread per 8 components
-    if (t >= n * 16) return;
+    if (t >= n_groups) return;
     const f32x4 *src = reinterpret_cast<const f32x4 *>(Ehat) + t * 2;
     const f32x4 e = src[0], o = src[1];  // even components k0 k2 k4 k6 | odd components k1 k3 k5 k7
     f16x8 h;
@@ -671,12 +671,12 @@ __device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) with a lit
     else static_assert(N == 0, "add the literal form for this count");
 }
 
-// NW waves, one 32-query set per wave (QW = 32*NW queries per workgroup).  A stage is TPS tiles of
-// 32 target rows x 128 fp16 components (8 KB each); the LDS ring holds NS stages and runs NS-1
-// stages ahead of the MFMAs: an fp16 tile is consumed in 256 MFMA cycles, far less than the LDS-DMA
-// latency.  The DMA is retired with a counted s_waitcnt vmcnt(N) and a raw s_barrier (a
-// __syncthreads() would make hipcc drain vmcnt(0) and serialise the ring).
-template <int NW, int NS, int TPS, int WPS>
+// NW waves, one 32-query set per wave (QW = 32*NW queries per workgroup).  The targets stream through
+// a two-stage LDS ring; a stage holds two "units" of 32 rows x 128 fp16 components (8 KB each):
+// two tiles at d <= 128, one tile at d <= 256, half a tile at d <= 512.  Two units per barrier was
+// the fastest geometry measured (deeper rings of one-unit stages lost: the barrier rate, not the DMA
+// latency, is what matters with fp16 tiles that are consumed in 256 MFMA cycles).
+template <int DP, int NW, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const _Float16 *__restrict__ Qh, int nq, const _Float16 *__restrict__ Th, int nt, int t_base,
     SegBounds segs, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared,
@@ -684,11 +684,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 64 * NW;
     constexpr int QW = 32 * NW;
-    constexpr int DP = 128;
-    constexpr int STAGE_BYTES = TPS * 32 * 256;
+    constexpr int NCH = DP / 128;            // 128-component chunks (= units) per tile
+    constexpr int UNIT_BYTES = 32 * 256;
+    constexpr int STAGE_BYTES = 2 * UNIT_BYTES;
+    constexpr int SP = NCH >= 2 ? NCH / 2 : 1;  // stages per loop iteration (keeps chunk numbers static)
     constexpr int SLOTS = 16;
-    u64 *lists = reinterpret_cast<u64 *>(smem + NS * STAGE_BYTES);
-    u64 *queues = reinterpret_cast<u64 *>(smem + NS * STAGE_BYTES + (size_t)K * QW * 8);
+    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES);
+    u64 *queues = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES + (size_t)K * QW * 8);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -698,11 +700,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const int qrow = qg < nq ? qg : nq - 1;
     unsigned *shared = tau_shared + qg;
 
-    f16x8 b[8];  // B fragments: k-step s covers components 16s + 8h .. 16s + 8h + 7
+    f16x8 b[NCH * 8];  // B fragments: chunk c, k-step s covers components 128c + 16s + 8h .. + 7
     {
         const f16x8 *qp = reinterpret_cast<const f16x8 *>(Qh + (size_t)qrow * DP);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) b[s] = qp[2 * s + h];
+        for (int i = 0; i < NCH * 8; ++i) b[i] = qp[2 * i + h];
     }
     for (int i = tid; i < K * QW; i += NT) lists[i] = KEY_INF;
     TopkState st;
@@ -711,83 +713,81 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     st.qcnt = 0;
     st.tau = topk_share(shared, KEY_INF, h);
     st.cfloor = sim_floor(st.tau);
-    wait_vmcnt<0>();  // nothing of mine in flight before the ring starts
 
     const int t_begin = segs.b[blockIdx.y];
     const int t_end = min(nt, segs.b[blockIdx.y + 1]);
     const int ntiles = (t_end - t_begin + 31) >> 5;
-    const int nstages = (ntiles + TPS - 1) / TPS;
+    const int nunits = ntiles * NCH;
+    const int nstages = (nunits + 1) >> 1;  // (a multiple of SP: NCH >= 2 makes nunits even)
 
-    constexpr int PPW = 8 * TPS / NW;  // 1 KiB LDS-DMA pieces per wave per stage
-    static_assert((8 * TPS) % NW == 0 && PPW >= 1 && PPW <= 4, "unsupported geometry");
+    constexpr int PPW = 16 / NW;  // 1 KiB LDS-DMA pieces per wave per stage
+    static_assert(16 % NW == 0, "unsupported wave count");
     auto issue_stage = [&](int it) {
-        const int trow0 = t_begin + it * 32 * TPS;
-        unsigned char *dst = smem + (it % NS) * STAGE_BYTES;
+        unsigned char *dst = smem + (it & 1) * STAGE_BYTES;
 #pragma unroll
         for (int u = 0; u < PPW; ++u) {
-            const int piece = wave + NW * u;
-            const int row = 4 * piece + (lane >> 4), pslot = lane & 15;
-            const int trow = min(trow0 + row, t_end - 1);
-            const _Float16 *src = Th + (size_t)trow * DP + (size_t)((pslot ^ (row & 15)) * 8);
+            const int piece = wave + NW * u;            // 0..15: unit piece>>3, rows 4*(piece&7)..+3
+            const int unit = 2 * it + (piece >> 3);
+            const int t = unit / NCH, c = unit % NCH;
+            const int row = 4 * (piece & 7) + (lane >> 4), pslot = lane & 15;
+            const int trow = min(t_begin + 32 * t + row, t_end - 1);
+            const _Float16 *src =
+                Th + (size_t)trow * DP + (size_t)(c * 128) + (size_t)((pslot ^ (row & 15)) * 8);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(dst + piece * 1024),
                                              16, 0, 0);
         }
     };
-    // wait until at most `newer` later stages of THIS wave are still outstanding
-    auto wait_ring = [&](int newer) {
-        if (NS >= 4 && newer >= 3) wait_vmcnt<3 * PPW>();
-        else if (NS >= 3 && newer == 2) wait_vmcnt<2 * PPW>();
-        else if (newer == 1) wait_vmcnt<PPW>();
-        else wait_vmcnt<0>();
-    };
-    auto ring_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    constexpr int AHEAD = NS - 1;
-#pragma unroll
-    for (int i = 0; i < AHEAD; ++i)
-        if (i < nstages) issue_stage(i);
-    wait_ring(min(AHEAD, nstages) - 1);  // stage 0 has landed
-    __syncthreads();                     // (drains everything once; also publishes the list set-up)
+    if (nstages > 0) issue_stage(0);
+    __syncthreads();  // (hipcc drains the DMA before the barrier; also publishes the list set-up)
 
-    for (int it = 0; it < nstages; ++it) {
-        if (it + AHEAD < nstages) issue_stage(it + AHEAD);  // its buffer was read in iteration it-1
+    f32x16 acc;
 #pragma unroll
-        for (int tt = 0; tt < TPS; ++tt) {
-            const int t = it * TPS + tt;
-            if (t < ntiles) {  // wave-uniform
-                f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int it0 = 0; it0 < nstages; it0 += SP) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                const f16x8 *sb =
-                    reinterpret_cast<const f16x8 *>(smem + (it % NS) * STAGE_BYTES) + (32 * tt + j) * SLOTS;
-                const int sw = j & 15;
+        for (int sp = 0; sp < SP; ++sp) {
+            const int it = it0 + sp;
+            if (it + 1 < nstages) issue_stage(it + 1);  // lands before the barrier below
 #pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb[(2 * s + h) ^ sw], b[s], acc, 0, 0, 0);
-                float mx = acc[0];
+            for (int uu = 0; uu < 2; ++uu) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int v = 2 * sp + uu;         // unit number inside this loop iteration (static)
+                const int c = v % NCH;             // static chunk number
+                const int unit = 2 * it + uu;
+                if (unit < nunits) {               // wave-uniform
+                    const int t = unit / NCH;
+                    if (c == 0) {
 #pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-                const int tile_row0 = t_begin + t * 32;
-                if (dbg & 1) {  // timing experiment: MFMA + fast path only
-                    if (mx > 3.0e38f) st.tau = mx;
-                } else if (__any(mx > st.cfloor))
-                    topk_append<NT, QW>(acc, st, lists, queues, shared, ql, K, tid, h, t_base + tile_row0,
-                                        t_end - tile_row0, false);
+                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    }
+                    const f16x8 *sb = reinterpret_cast<const f16x8 *>(smem + (it & 1) * STAGE_BYTES +
+                                                                      uu * UNIT_BYTES) + j * SLOTS;
+                    const int sw = j & 15;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb[(2 * s + h) ^ sw], b[c * 8 + s], acc,
+                                                                     0, 0, 0);
+                    if (c == NCH - 1) {
+                        float mx = acc[0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+                        const int tile_row0 = t_begin + t * 32;
+                        if (dbg & 1) {  // timing experiment: MFMA + fast path only
+                            if (mx > 3.0e38f) st.tau = mx;
+                        } else if (__any(mx > st.cfloor))
+                            topk_append<NT, QW>(acc, st, lists, queues, shared, ql, K, tid, h,
+                                                t_base + tile_row0, t_end - tile_row0, false);
+                    }
+                }
             }
+            if ((it & 15) == 15) {
+                st.tau = topk_share(shared, st.taukey, h);
+                st.cfloor = sim_floor(st.tau);
+            }
+            __syncthreads();  // stage it+1 is complete (all waves' pieces) before anyone reads it
         }
-        if ((it & 15) == 15) {
-            st.tau = topk_share(shared, st.taukey, h);
-            st.cfloor = sim_floor(st.tau);
-        }
-        // stage it+1 must be complete (all waves' pieces) before anyone reads it; stages it+2 ..
-        // it+AHEAD stay in flight
-        const int newer = min(it + AHEAD, nstages - 1) - (it + 1);
-        wait_ring(newer < 0 ? 0 : newer);
-        ring_barrier();
     }
     if (__any(st.qcnt > 0)) st = topk_flush<NT, QW>(st, lists, queues, shared, ql, K, tid, h, false);
     __syncthreads();
@@ -1202,9 +1202,12 @@ static const KnnShape kShapes[] = {
     {128, 2, 4, 2, 0},  // 256 queries/WG, <=256 VGPRs, up to 2 WG/CU
     {256, 1, 8, 2, 0},  // 256 queries/WG, <=256 VGPRs, 1 WG/CU
     {512, 1, 4, 1, 0},  // 128 queries/WG, one wave per SIMD: 512 registers per lane (256 of them queries)
-    {128, 1, 4, 3, 4},  // fp16 prefilter: 128 queries/WG, LDS ring of 4 one-tile stages
+    {128, 1, 4, 3, 4},  // fp16 prefilter, d <= 128: 128 queries/WG, 32 KB LDS ring
+    {256, 1, 4, 2, 4},  // fp16 prefilter, d <= 256
+    {512, 1, 4, 2, 4},  // fp16 prefilter, d <= 512 (128 VGPRs of queries)
 };
-#define FDR_SHAPE_PREFILTER 5
+#define FDR_SHAPE_PREFILTER 5  // + 0 / 1 / 2 for d <= 128 / 256 / 512
+static int prefilter_shape(int dp) { return FDR_SHAPE_PREFILTER + (dp == 128 ? 0 : (dp == 256 ? 1 : 2)); }
 
 static size_t knn_lds_bytes(const KnnShape &sh, int k) {
     const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
@@ -1371,7 +1374,8 @@ static bool knn_prefilter_wanted(const fdr_ctx *ctx, int dp, int64_t nt, int k) 
     }
     if (mode == FDR_MODE_EXACT) return false;
     const int kp = (k + prefilter_extra() + 1) & ~1;
-    if (!(dp == 128 && kp <= FDR_MAX_K && nt >= kp)) return false;
+    if (!(kp <= FDR_MAX_K && nt >= kp)) return false;
+    if (knn_lds_bytes(kShapes[prefilter_shape(dp)], kp) > 160 * 1024) return false;
     return mode == FDR_MODE_PREFILTER || nt >= 8192;
 }
 
@@ -1388,18 +1392,19 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.kp = (k + prefilter_extra() + 1) & ~1;
     L.chunk = (int)std::min<int64_t>(nq, 16384);
     const size_t exact_all = knn_plan(ctx, nq, nt, d, k).total_bytes;
-    const size_t pre = knn_plan(ctx, nq, nt, d, L.kp, FDR_SHAPE_PREFILTER).total_bytes;
+    const int dp = fdr_padded_dim(d);
+    const size_t pre = knn_plan(ctx, nq, nt, d, L.kp, prefilter_shape(dp)).total_bytes;
     // any exact plan for <= chunk queries: bits + bound words + at most FDR_MAX_SEG segments of lists
     const size_t chunk_bound = align256((size_t)((nt + 31) / 32) * 4) + align256((size_t)(L.chunk + 128) * 4) +
                                (size_t)FDR_MAX_SEG * (L.chunk + 128) * (size_t)k * 8;
     L.knn_bytes = align256(std::max(exact_all, std::max(pre, chunk_bound)));
     size_t o = L.knn_bytes;
-    L.off_ht = o;       o += align256((size_t)nt * 128 * 2);
-    L.off_hq = o;       o += align256((size_t)nq * 128 * 2);
+    L.off_ht = o;       o += align256((size_t)nt * dp * 2);
+    L.off_hq = o;       o += align256((size_t)nq * dp * 2);
     L.off_cand = o;     o += align256((size_t)nq * L.kp * 8);
     L.off_counter = o;  o += 256;
     L.off_flagged = o;  o += align256((size_t)nq * 4);
-    L.off_qc = o;       o += align256((size_t)L.chunk * 128 * 4);
+    L.off_qc = o;       o += align256((size_t)L.chunk * dp * 4);
     L.off_qzc = o;      o += align256((size_t)L.chunk);
     L.off_idxc = o;     o += align256((size_t)L.chunk * k * 4);
     L.off_distc = o;    o += align256((size_t)L.chunk * k * 4);
@@ -1500,18 +1505,19 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     float *d_distc = reinterpret_cast<float *>(ws + L.off_distc);
     const int kp = L.kp;
 
-    const KnnPlan p = knn_plan(ctx, nq, nt, d, kp, FDR_SHAPE_PREFILTER);
-    const KnnShape &sh = kShapes[FDR_SHAPE_PREFILTER];
+    const int dp = fdr_padded_dim(d);
+    const KnnPlan p = knn_plan(ctx, nq, nt, d, kp, prefilter_shape(dp));
+    const KnnShape &sh = kShapes[prefilter_shape(dp)];
     unsigned *d_bits = reinterpret_cast<unsigned *>(ws);
     unsigned *d_shared = reinterpret_cast<unsigned *>(ws + p.bits_bytes);
     u64 *d_partial = reinterpret_cast<u64 *>(ws + p.bits_bytes + p.shared_bytes);
 
     int trc = timing_begin(ctx, FDR_KERNEL_KNN_RERANK, st);  // conversion + set-up count as "rerank"
     if (trc) return trc;
-    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nt * 16 + 255) / 256)), dim3(256), 0, st, d_That,
-                       (long long)nt, d_ht);
-    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nq * 16 + 255) / 256)), dim3(256), 0, st, d_Qhat,
-                       (long long)nq, d_hq);
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nt * (dp / 8) + 255) / 256)), dim3(256), 0, st, d_That,
+                       (long long)nt * (dp / 8), d_ht);
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nq * (dp / 8) + 255) / 256)), dim3(256), 0, st, d_Qhat,
+                       (long long)nq * (dp / 8), d_hq);
     hipLaunchKernelGGL(pack_zero_bits_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st,
                        d_tzero, (int)nt, d_bits, d_shared, p.nq_pad);
     HIP_TRY(hipGetLastError());
@@ -1520,19 +1526,17 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     const int pdbg = getenv("FDR_KNN_DEBUG") ? atoi(getenv("FDR_KNN_DEBUG")) : 0;
-    const int ring = getenv("FDR_KNN_RING") ? atoi(getenv("FDR_KNN_RING")) : 0;  // development knob
-#define FDR_LAUNCH_PRE(NS_, TPS_)                                                                       \
+#define FDR_LAUNCH_PRE(DP_, WPS_)                                                                       \
     do {                                                                                                \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<4, NS_, TPS_, 3>), \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<DP_, 4, WPS_>),  \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL((knn_prefilter_kernel<4, NS_, TPS_, 3>), dim3((unsigned)p.nqb, (unsigned)p.nseg), \
+        hipLaunchKernelGGL((knn_prefilter_kernel<DP_, 4, WPS_>), dim3((unsigned)p.nqb, (unsigned)p.nseg), \
                            dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp,   \
                            p.nq_pad, d_partial, d_shared, pdbg);                                        \
     } while (0)
-    if (ring == 41) FDR_LAUNCH_PRE(4, 1);       // four one-tile stages
-    else if (ring == 31) { FDR_LAUNCH_PRE(3, 1); }  // (LDS is sized for 32 KB of ring in every variant)
-    else if (ring == 21) { FDR_LAUNCH_PRE(2, 1); }
-    else FDR_LAUNCH_PRE(2, 2);                  // two two-tile stages
+    if (dp == 128) FDR_LAUNCH_PRE(128, 3);
+    else if (dp == 256) FDR_LAUNCH_PRE(256, 2);
+    else FDR_LAUNCH_PRE(512, 2);
 #undef FDR_LAUNCH_PRE
     HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
@@ -1544,7 +1548,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     HIP_TRY(hipMemsetAsync(d_counter, 0, 4, st));
     const float margin = 2.0f * FDR_PREFILTER_EPS + 4.0e-7f;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
-                       (const u64 *)d_cand, kp, k, d_Qhat, d_That, (int)nq, 128, (int)t_base, margin, d_idx,
+                       (const u64 *)d_cand, kp, k, d_Qhat, d_That, (int)nq, dp, (int)t_base, margin, d_idx,
                        d_dist, d_counter, d_flagged);
     HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
@@ -1562,7 +1566,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     for (int first = 0; first < count; first += L.chunk) {
         const int c = std::min(L.chunk, count - first);
         hipLaunchKernelGGL(gather_queries_kernel, dim3((unsigned)c), dim3(256), 0, st, d_Qhat, d_qzero,
-                           (const int *)d_flagged, first, c, 128, d_qc, d_qzc);
+                           (const int *)d_flagged, first, c, dp, d_qc, d_qzc);
         HIP_TRY(hipGetLastError());
         int rc = launch_knn_exact(ctx, d_qc, d_qzc, c, d_That, d_tzero, nt, t_base, d, k, d_idxc, d_distc,
                                   d_ws, L.knn_bytes, st);

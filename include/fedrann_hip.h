@@ -117,7 +117,7 @@ int fdr_timing(fdr_ctx *ctx, int enable);
 int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out);
 /* ---- k-NN mode ---------------------------------------------------------------------------------
  * Both modes return the SAME canonical result.  EXACT: every pair through the
- * fp32 MFMA kernel.  PREFILTER (d <= 128, k <= 56): an fp16 MFMA pass proposes k + 8 candidates per
+ * fp32 MFMA kernel.  PREFILTER (k <= 56): an fp16 MFMA pass proposes k + 8 candidates per
  * query; a certificate proves they contain the exact top-k and their distances are recomputed with
  * the canonical fp32 chain; queries that cannot be certified are searched by the exact kernel.  The
  * prefilter mode reads one 4-byte counter back per call (a stream synchronisation).  AUTO (default):
