@@ -251,6 +251,7 @@ struct TopkState {
     float cfloor; // sim_floor(tau)
     int taupos;   // position of taukey in the list
     int qcnt;     // entries in this LANE's append queue
+    float foreign;  // last cross-segment bound seen (strict form, +inf if none): see topk_share
 };
 
 // Cross-segment bound.  Workgroups that search different target segments for the same queries
@@ -260,7 +261,8 @@ struct TopkState {
 // the final top-k; candidates with dist == bound are kept (ties are decided by index in the merge):
 // the admission test is dist < nextup(bound).  A stale or missing value only admits more candidates,
 // so the result does not depend on scheduling, timing or placement.
-__device__ __forceinline__ float topk_share(unsigned *__restrict__ slot, const u64 taukey, const int h) {
+__device__ __forceinline__ float topk_share(unsigned *__restrict__ slot, const u64 taukey, const int h,
+                                            float &foreign_out) {
     const unsigned mine = (unsigned)(taukey >> 32);  // 0x7F800000 while the list still has empty slots
     unsigned seen = mine;
     if (h == 0) {
@@ -273,6 +275,7 @@ __device__ __forceinline__ float topk_share(unsigned *__restrict__ slot, const u
     // strict bound: the list's own maximum admits dist < tau; a foreign bound admits dist <= bound
     const float own = __uint_as_float(mine);
     const float foreign = seen < 0x7F800000u ? __uint_as_float(seen + 1u) : __builtin_inff();
+    foreign_out = foreign;
     return fminf(own, foreign);
 }
 
@@ -323,7 +326,9 @@ __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lis
             }
         }
     }
-    st.tau = topk_share(shared, st.taukey, h);
+    // (no atomic here: a flush must not wait for a global round trip; the bound is exchanged by the
+    // periodic topk_share calls of the tile loop)
+    st.tau = fminf(__uint_as_float((unsigned)(st.taukey >> 32)), st.foreign);
     st.cfloor = sim_floor(st.tau);
     st.qcnt = 0;
     return st;
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
         st[s].taukey = KEY_INF;
         st[s].taupos = 0;
         st[s].qcnt = 0;
-        st[s].tau = topk_share((tau_shared + qslot[s]), KEY_INF, h);  // other segments may already have a bound
+        st[s].tau = topk_share((tau_shared + qslot[s]), KEY_INF, h, st[s].foreign);  // other segments may already have a bound
         st[s].cfloor = sim_floor(st[s].tau);
     }
 
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
                         topk_append<NT, QW>(acc[s], st[s], lists, queues + s * QCAP * NT, (tau_shared + qslot[s]), ql[s],
                                             K, tid, h, t_base + tile_row0, t_end - tile_row0, (dbg & 2) != 0);
                     if ((t & 31) == 31 && !(dbg & 4)) {  // refresh the cross-segment bound now and then
-                        st[s].tau = topk_share((tau_shared + qslot[s]), st[s].taukey, h);
+                        st[s].tau = topk_share((tau_shared + qslot[s]), st[s].taukey, h, st[s].foreign);
                         st[s].cfloor = sim_floor(st[s].tau);
                     }
                 }
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     st.taukey = KEY_INF;
     st.taupos = 0;
     st.qcnt = 0;
-    st.tau = topk_share(shared, KEY_INF, h);
+    st.tau = topk_share(shared, KEY_INF, h, st.foreign);
     st.cfloor = sim_floor(st.tau);
 
     const int t_begin = segs.b[blockIdx.y];
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
                 }
             }
             if ((it & 15) == 15) {
-                st.tau = topk_share(shared, st.taukey, h);
+                st.tau = topk_share(shared, st.taukey, h, st.foreign);
                 st.cfloor = sim_floor(st.tau);
             }
             __syncthreads();  // stage it+1 is complete (all waves' pieces) before anyone reads it
