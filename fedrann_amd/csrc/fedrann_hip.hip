@@ -850,12 +850,16 @@ __global__ __launch_bounds__(256) void knn_merge_keys_kernel(const u64 *__restri
 // P2: certificate + exact re-rank.  One wave per query, one lane per candidate.
 __global__ __launch_bounds__(256) void knn_rerank_kernel(
     const u64 *__restrict__ cand, int KP, int K, const float *__restrict__ Qhat,
-    const float *__restrict__ That, int nq, int DP, int t_base, float margin,
-    int *__restrict__ idx_out, float *__restrict__ dist_out, int *__restrict__ counter,
+    const unsigned char *__restrict__ qzero, const float *__restrict__ That, int nq, int DP, int t_base,
+    float margin, int *__restrict__ idx_out, float *__restrict__ dist_out, int *__restrict__ counter,
     int *__restrict__ flagged) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
+    if (qzero[q]) {  // all-zero query: closed-form answer (zero_answer_kernel); listed from the back
+        if (lane == 0) flagged[nq - 1 - atomicAdd(counter + 1, 1)] = q;
+        return;
+    }
     u64 key = KEY_INF;
     if (lane < KP) key = cand[(size_t)q * KP + lane];
     const float dt = __uint_as_float((unsigned)(key >> 32));
@@ -899,6 +903,69 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
         idx_out[(size_t)q * K + lane] = (int)(unsigned)(mine & 0xffffffffull);
         dist_out[(size_t)q * K + lane] = __uint_as_float((unsigned)(mine >> 32));
     }
+}
+
+// The neighbours of an all-zero query do not depend on the query: the all-zero targets at distance 0
+// in index order, then every other target at distance 1 in index order.  One workgroup scans the
+// zero flags for the first K rows of each kind (stops as soon as K zero rows are known).
+__global__ __launch_bounds__(1024) void zero_answer_kernel(const unsigned char *__restrict__ tzero, int nt,
+                                                           int t_base, int K, int *__restrict__ zidx,
+                                                           float *__restrict__ zdist) {
+    __shared__ int wz[16], wnz[16];
+    __shared__ int zlist[FDR_MAX_K], nzlist[FDR_MAX_K];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int zc = 0, nzc = 0;  // found so far (uniform)
+    for (int base = 0; base < nt && zc < K; base += 1024) {
+        const int row = base + tid;
+        const bool in = row < nt;
+        const bool z = in && tzero[row] != 0, nz = in && !z;
+        const u64 bz = __ballot(z), bnz = __ballot(nz);
+        if (lane == 0) {
+            wz[wave] = __popcll(bz);
+            wnz[wave] = __popcll(bnz);
+        }
+        __syncthreads();
+        int pz = zc, pnz = nzc, tz = 0, tnz = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) {
+                pz += wz[w];
+                pnz += wnz[w];
+            }
+            tz += wz[w];
+            tnz += wnz[w];
+        }
+        const u64 below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        if (z) {
+            const int pos = pz + __popcll(bz & below);
+            if (pos < K) zlist[pos] = row;
+        }
+        if (nz) {
+            const int pos = pnz + __popcll(bnz & below);
+            if (pos < K) nzlist[pos] = row;
+        }
+        zc += tz;
+        nzc += tnz;
+        __syncthreads();
+    }
+    if (zc > K) zc = K;
+    if (tid < K) {
+        const bool from_zero = tid < zc;
+        zidx[tid] = t_base + (from_zero ? zlist[tid] : nzlist[tid - zc]);
+        zdist[tid] = from_zero ? 0.0f : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_zero_answer_kernel(const int *__restrict__ zidx,
+                                                                  const float *__restrict__ zdist,
+                                                                  const int *__restrict__ list, int count,
+                                                                  int K, int *__restrict__ idx_out,
+                                                                  float *__restrict__ dist_out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= count * K) return;
+    const int i = t / K, e = t - i * K;
+    const int q = list[i];
+    idx_out[(size_t)q * K + e] = zidx[e];
+    dist_out[(size_t)q * K + e] = zdist[e];
 }
 
 __global__ __launch_bounds__(256) void gather_queries_kernel(const float *__restrict__ Qhat,
@@ -1407,7 +1474,7 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.off_ht = o;       o += align256((size_t)nt * dp * 2);
     L.off_hq = o;       o += align256((size_t)nq * dp * 2);
     L.off_cand = o;     o += align256((size_t)nq * L.kp * 8);
-    L.off_counter = o;  o += 256;
+    L.off_counter = o;  o += 1024;  // [0] uncertified, [1] all-zero queries; zero answer idx at +256, dist at +512
     L.off_flagged = o;  o += align256((size_t)nq * 4);
     L.off_qc = o;       o += align256((size_t)L.chunk * dp * 4);
     L.off_qzc = o;      o += align256((size_t)L.chunk);
@@ -1550,22 +1617,34 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
                        (const u64 *)d_partial, p.nseg, (int)nq, p.nq_pad, kp, d_cand);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(d_counter, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(d_counter, 0, 8, st));
     const float margin = 2.0f * FDR_PREFILTER_EPS + 4.0e-7f;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
-                       (const u64 *)d_cand, kp, k, d_Qhat, d_That, (int)nq, dp, (int)t_base, margin, d_idx,
-                       d_dist, d_counter, d_flagged);
+                       (const u64 *)d_cand, kp, k, d_Qhat, d_qzero, d_That, (int)nq, dp, (int)t_base, margin,
+                       d_idx, d_dist, d_counter, d_flagged);
     HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
 
-    // how many queries could not be certified?  (one 4-byte read-back; the exact passes below are
-    // sized from it)
-    int count = 0;
-    HIP_TRY(hipMemcpyAsync(&count, d_counter, 4, hipMemcpyDeviceToHost, st));
+    // how many queries could not be certified / are all-zero?  (one 8-byte read-back; the passes below
+    // are sized from it)
+    int counts[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(counts, d_counter, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    int count = counts[0];
+    const int zcount = counts[1];
     ctx->last_flagged = count;
+    if (zcount > 0) {  // all-zero queries share one closed-form answer
+        int *d_zidx = d_counter + 64;
+        float *d_zdist = reinterpret_cast<float *>(d_counter + 128);
+        hipLaunchKernelGGL(zero_answer_kernel, dim3(1), dim3(1024), 0, st, d_tzero, (int)nt, (int)t_base, k,
+                           d_zidx, d_zdist);
+        hipLaunchKernelGGL(scatter_zero_answer_kernel, dim3((unsigned)(((int64_t)zcount * k + 255) / 256)),
+                           dim3(256), 0, st, (const int *)d_zidx, (const float *)d_zdist,
+                           (const int *)(d_flagged + (nq - zcount)), zcount, k, d_idx, d_dist);
+        HIP_TRY(hipGetLastError());
+    }
     if (count <= 0) return FDR_OK;
-    if ((int64_t)count * 2 > nq)  // the prefilter did not help on this input: one exact pass for everyone
+    if ((int64_t)count * 2 > nq - zcount)  // the prefilter did not help on this input: exact pass for everyone
         return launch_knn_exact(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
                                 d_ws, L.knn_bytes, st);
     for (int first = 0; first < count; first += L.chunk) {
