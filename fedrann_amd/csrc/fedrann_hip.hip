@@ -681,7 +681,7 @@ __device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) with a lit
 // two tiles at d <= 128, one tile at d <= 256, half a tile at d <= 512.  Two units per barrier was
 // the fastest geometry measured (deeper rings of one-unit stages lost: the barrier rate, not the DMA
 // latency, is what matters with fp16 tiles that are consumed in 256 MFMA cycles).
-template <int DP, int NW, int WPS>
+template <int DP, int NW, int WPS, int U>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const _Float16 *__restrict__ Qh, int nq, const _Float16 *__restrict__ Th, int nt, int t_base,
     SegBounds segs, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared,
@@ -691,8 +691,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     constexpr int QW = 32 * NW;
     constexpr int NCH = DP / 128;            // 128-component chunks (= units) per tile
     constexpr int UNIT_BYTES = 32 * 256;
-    constexpr int STAGE_BYTES = 2 * UNIT_BYTES;
-    constexpr int SP = NCH >= 2 ? NCH / 2 : 1;  // stages per loop iteration (keeps chunk numbers static)
+    constexpr int STAGE_BYTES = U * UNIT_BYTES;  // U units per stage
+    constexpr int SP = NCH >= U ? NCH / U : 1;  // stages per loop iteration (keeps chunk numbers static)
     constexpr int SLOTS = 16;
     u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES);
     u64 *queues = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES + (size_t)K * QW * 8);
@@ -723,16 +723,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const int t_end = min(nt, segs.b[blockIdx.y + 1]);
     const int ntiles = (t_end - t_begin + 31) >> 5;
     const int nunits = ntiles * NCH;
-    const int nstages = (nunits + 1) >> 1;  // (a multiple of SP: NCH >= 2 makes nunits even)
+    const int nstages = (nunits + U - 1) / U;  // (a multiple of SP)
 
-    constexpr int PPW = 16 / NW;  // 1 KiB LDS-DMA pieces per wave per stage
-    static_assert(16 % NW == 0, "unsupported wave count");
+    constexpr int PPW = 8 * U / NW;  // 1 KiB LDS-DMA pieces per wave per stage
+    static_assert((8 * U) % NW == 0, "unsupported wave count");
     auto issue_stage = [&](int it) {
         unsigned char *dst = smem + (it & 1) * STAGE_BYTES;
 #pragma unroll
         for (int u = 0; u < PPW; ++u) {
             const int piece = wave + NW * u;            // 0..15: unit piece>>3, rows 4*(piece&7)..+3
-            const int unit = 2 * it + (piece >> 3);
+            const int unit = U * it + (piece >> 3);
             const int t = unit / NCH, c = unit % NCH;
             const int row = 4 * (piece & 7) + (lane >> 4), pslot = lane & 15;
             const int trow = min(t_begin + 32 * t + row, t_end - 1);
@@ -755,12 +755,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
             const int it = it0 + sp;
             if (it + 1 < nstages) issue_stage(it + 1);  // lands before the barrier below
 #pragma unroll
-            for (int uu = 0; uu < 2; ++uu) {
+            for (int uu = 0; uu < U; ++uu) {
                 constexpr int dummy = 0;
                 (void)dummy;
-                const int v = 2 * sp + uu;         // unit number inside this loop iteration (static)
+                const int v = U * sp + uu;         // unit number inside this loop iteration (static)
                 const int c = v % NCH;             // static chunk number
-                const int unit = 2 * it + uu;
+                const int unit = U * it + uu;
                 if (unit < nunits) {               // wave-uniform
                     const int t = unit / NCH;
                     if (c == 0) {
@@ -1277,9 +1277,16 @@ static const KnnShape kShapes[] = {
     {128, 1, 4, 3, 4},  // fp16 prefilter, d <= 128: 128 queries/WG, 32 KB LDS ring
     {256, 1, 4, 2, 4},  // fp16 prefilter, d <= 256
     {512, 1, 4, 2, 4},  // fp16 prefilter, d <= 512 (128 VGPRs of queries)
+    {128, 1, 4, 3, 2},  // fp16 prefilter, d <= 128, one-unit stages (16 KB ring): a third workgroup per CU
 };
 #define FDR_SHAPE_PREFILTER 5  // + 0 / 1 / 2 for d <= 128 / 256 / 512
-static int prefilter_shape(int dp) { return FDR_SHAPE_PREFILTER + (dp == 128 ? 0 : (dp == 256 ? 1 : 2)); }
+static int prefilter_shape(int dp) {
+    if (dp == 128) {
+        const char *e = getenv("FDR_KNN_RING");  // development knob: 1 = one-unit stages
+        return (e && atoi(e) == 1) ? FDR_SHAPE_PREFILTER + 3 : FDR_SHAPE_PREFILTER;
+    }
+    return FDR_SHAPE_PREFILTER + (dp == 256 ? 1 : 2);
+}
 
 static size_t knn_lds_bytes(const KnnShape &sh, int k) {
     const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
@@ -1598,17 +1605,18 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     const int pdbg = getenv("FDR_KNN_DEBUG") ? atoi(getenv("FDR_KNN_DEBUG")) : 0;
-#define FDR_LAUNCH_PRE(DP_, WPS_)                                                                       \
+#define FDR_LAUNCH_PRE(DP_, WPS_, U_)                                                                   \
     do {                                                                                                \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<DP_, 4, WPS_>),  \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<DP_, 4, WPS_, U_>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL((knn_prefilter_kernel<DP_, 4, WPS_>), dim3((unsigned)p.nqb, (unsigned)p.nseg), \
+        hipLaunchKernelGGL((knn_prefilter_kernel<DP_, 4, WPS_, U_>), dim3((unsigned)p.nqb, (unsigned)p.nseg), \
                            dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp,   \
                            p.nq_pad, d_partial, d_shared, pdbg);                                        \
     } while (0)
-    if (dp == 128) FDR_LAUNCH_PRE(128, 3);
-    else if (dp == 256) FDR_LAUNCH_PRE(256, 2);
-    else FDR_LAUNCH_PRE(512, 2);
+    if (dp == 128 && sh.tps == 2) FDR_LAUNCH_PRE(128, 3, 1);
+    else if (dp == 128) FDR_LAUNCH_PRE(128, 3, 2);
+    else if (dp == 256) FDR_LAUNCH_PRE(256, 2, 2);
+    else FDR_LAUNCH_PRE(512, 2, 2);
 #undef FDR_LAUNCH_PRE
     HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
