@@ -678,9 +678,9 @@ __device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) with a lit
 
 // NW waves, one 32-query set per wave (QW = 32*NW queries per workgroup).  The targets stream through
 // a two-stage LDS ring; a stage holds two "units" of 32 rows x 128 fp16 components (8 KB each):
-// two tiles at d <= 128, one tile at d <= 256, half a tile at d <= 512.  Two units per barrier was
-// the fastest geometry measured (deeper rings of one-unit stages lost: the barrier rate, not the DMA
-// latency, is what matters with fp16 tiles that are consumed in 256 MFMA cycles).
+// U units per stage.  What matters most is how many workgroups share a CU (their MFMAs fill the waits
+// at each other's per-stage barriers): at d <= 128 one-unit stages (16 KB ring, three workgroups per CU)
+// beat two-unit stages (32 KB, two per CU) 5.5 ms to 7.7 ms; deeper rings of the same total size lost.
 template <int DP, int NW, int WPS, int U>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const _Float16 *__restrict__ Qh, int nq, const _Float16 *__restrict__ Th, int nt, int t_base,
@@ -1282,8 +1282,11 @@ static const KnnShape kShapes[] = {
 #define FDR_SHAPE_PREFILTER 5  // + 0 / 1 / 2 for d <= 128 / 256 / 512
 static int prefilter_shape(int dp) {
     if (dp == 128) {
-        const char *e = getenv("FDR_KNN_RING");  // development knob: 1 = one-unit stages
-        return (e && atoi(e) == 1) ? FDR_SHAPE_PREFILTER + 3 : FDR_SHAPE_PREFILTER;
+        // one-unit stages (16 KB ring) leave room for a third workgroup per CU, which is what hides
+        // the waits at the per-stage barrier: 5.5 ms vs 7.7 ms at 100 k rows.  FDR_KNN_RING=2 selects
+        // the two-unit form (development knob).
+        const char *e = getenv("FDR_KNN_RING");
+        return (e && atoi(e) == 2) ? FDR_SHAPE_PREFILTER : FDR_SHAPE_PREFILTER + 3;
     }
     return FDR_SHAPE_PREFILTER + (dp == 256 ? 1 : 2);
 }
