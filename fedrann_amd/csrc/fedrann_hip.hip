@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     const u64 *__restrict__ cand, int KP, int K, const float *__restrict__ Qhat,
     const unsigned char *__restrict__ qzero, const float *__restrict__ That, int nq, int DP, int t_base,
     float margin, int *__restrict__ idx_out, float *__restrict__ dist_out, int *__restrict__ counter,
-    int *__restrict__ flagged) {
+    int *__restrict__ flagged, int *__restrict__ range_list, float *__restrict__ theta) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -866,7 +866,14 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     const float dK = __shfl(dt, K - 1), dKP = __shfl(dt, KP - 1);
     const bool valid = (dK + margin < 1.0f) && (dK + margin < dKP);
     if (!valid) {
-        if (lane == 0) flagged[atomicAdd(counter, 1)] = q;
+        if (lane == 0) {
+            if (range_list && dK + margin < 1.0f) {  // plateau: collect {d~ <= d~(K) + M} in a range pass
+                range_list[atomicAdd(counter + 2, 1)] = q;
+                theta[q] = dK + margin;
+            } else {
+                flagged[atomicAdd(counter, 1)] = q;
+            }
+        }
         return;
     }
     u64 exact = ~0ull;
@@ -902,6 +909,180 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     if (lane < K) {
         idx_out[(size_t)q * K + lane] = (int)(unsigned)(mine & 0xffffffffull);
         dist_out[(size_t)q * K + lane] = __uint_as_float((unsigned)(mine >> 32));
+    }
+}
+
+// ---- range pass for uncertified queries --------------------------------------------------------
+// A query whose K' candidates could not be certified usually sits on a plateau of (near-)ties wider
+// than K' (rows with one or two non-zero components have hundreds of exact duplicates).  Its exact
+// top-K is still contained in { targets with d~ <= theta }, theta = d~(K) + M (same lemma as the
+// certificate, which does not need the K' list to be complete), as long as theta < 1.  This pass
+// re-streams the fp16 targets for those queries only and collects that set (no top-k state at all, so
+// it runs at the MFMA / staging rate); knn_rerank_long_kernel then ranks it with the canonical fp32
+// chain.  Queries whose set exceeds RANGE_CAP fall back to the exact kernel.
+#define RANGE_CAP 1024
+
+template <int DP, int NW, int WPS>
+__global__ __launch_bounds__(64 * NW, WPS) void knn_range_kernel(
+    const _Float16 *__restrict__ Qh, const float *__restrict__ theta, int nq,
+    const _Float16 *__restrict__ Th, int nt, int t_base, SegBounds segs, int *__restrict__ cnt,
+    int *__restrict__ cand) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int QW = 32 * NW;
+    constexpr int NCH = DP / 128;
+    constexpr int UNIT_BYTES = 32 * 256;
+    constexpr int SLOTS = 16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int qg = blockIdx.x * QW + wave * 32 + j;
+    const bool live = qg < nq;
+    const int qrow = live ? qg : nq - 1;
+    const float th = live ? theta[qrow] : -1.0f;          // admit d~ <= th
+    const float sfloor = live ? (1.0f - th) - 3.0e-7f : __builtin_inff();  // conservative similarity form
+
+    f16x8 b[NCH * 8];
+    {
+        const f16x8 *qp = reinterpret_cast<const f16x8 *>(Qh + (size_t)qrow * DP);
+#pragma unroll
+        for (int i = 0; i < NCH * 8; ++i) b[i] = qp[2 * i + h];
+    }
+    const int t_begin = segs.b[blockIdx.y];
+    const int t_end = min(nt, segs.b[blockIdx.y + 1]);
+    const int ntiles = (t_end - t_begin + 31) >> 5;
+    const int nunits = ntiles * NCH;  // one unit per stage, two-stage ring
+
+    constexpr int PPW = 8 / NW;
+    static_assert(8 % NW == 0, "unsupported wave count");
+    auto issue_stage = [&](int it) {
+        unsigned char *dst = smem + (it & 1) * UNIT_BYTES;
+        const int t = it / NCH, c = it % NCH;
+#pragma unroll
+        for (int u = 0; u < PPW; ++u) {
+            const int piece = wave + NW * u;
+            const int row = 4 * piece + (lane >> 4), pslot = lane & 15;
+            const int trow = min(t_begin + 32 * t + row, t_end - 1);
+            const _Float16 *src =
+                Th + (size_t)trow * DP + (size_t)(c * 128) + (size_t)((pslot ^ (row & 15)) * 8);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + piece * 1024),
+                                             16, 0, 0);
+        }
+    };
+    if (nunits > 0) issue_stage(0);
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int it0 = 0; it0 < nunits; it0 += NCH) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int it = it0 + c;
+            if (it + 1 < nunits) issue_stage(it + 1);
+            if (c == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
+            const f16x8 *sb = reinterpret_cast<const f16x8 *>(smem + (it & 1) * UNIT_BYTES) + j * SLOTS;
+            const int sw = j & 15;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb[(2 * s2 + h) ^ sw], b[c * 8 + s2], acc, 0, 0, 0);
+            if (c == NCH - 1) {
+                float mx = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+                if (__any(mx > sfloor)) {
+                    const int t = it / NCH;
+                    const int row0 = t_begin + 32 * t + 4 * h;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (acc[r] > sfloor) {
+                            float a = acc[r];
+                            asm volatile("" : "+v"(a));
+                            const int row = row0 + (r & 3) + 8 * (r >> 2);
+                            if (dist_from_sim(a) <= th && row < t_end) {
+                                const int pos = atomicAdd(cnt + qg, 1);
+                                if (pos < RANGE_CAP) cand[(size_t)qg * RANGE_CAP + pos] = t_base + row;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// exact ranking of a collected range: one wave per query, keys staged in LDS
+__global__ __launch_bounds__(256) void knn_rerank_long_kernel(
+    const int *__restrict__ list, int count, const int *__restrict__ cnt, const int *__restrict__ cand,
+    int K, const float *__restrict__ Qhat, const float *__restrict__ That, int DP, int t_base,
+    int *__restrict__ idx_out, float *__restrict__ dist_out, int *__restrict__ counter,
+    int *__restrict__ flagged) {
+    __shared__ u64 keys[4][RANGE_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= count) return;
+    const int q = list[i];
+    const int n = cnt[i];
+    if (n > RANGE_CAP || n < K) {  // set too large (or, defensively, too small): exact kernel
+        if (lane == 0) flagged[atomicAdd(counter, 1)] = q;
+        return;
+    }
+    const f32x4 *qp = reinterpret_cast<const f32x4 *>(Qhat + (size_t)q * DP);
+    for (int m = lane; m < n; m += 64) {
+        const int tidx = cand[(size_t)i * RANGE_CAP + m];
+        const f32x4 *tp = reinterpret_cast<const f32x4 *>(That + (size_t)(tidx - t_base) * DP);
+        float c = 0.0f;
+        for (int g = 0; g < DP / 8; ++g) {  // canonical chain, ascending components
+            const f32x4 qe = qp[2 * g], qo = qp[2 * g + 1], te = tp[2 * g], to = tp[2 * g + 1];
+            c = __builtin_fmaf(qe.x, te.x, c);
+            c = __builtin_fmaf(qo.x, to.x, c);
+            c = __builtin_fmaf(qe.y, te.y, c);
+            c = __builtin_fmaf(qo.y, to.y, c);
+            c = __builtin_fmaf(qe.z, te.z, c);
+            c = __builtin_fmaf(qo.z, to.z, c);
+            c = __builtin_fmaf(qe.w, te.w, c);
+            c = __builtin_fmaf(qo.w, to.w, c);
+        }
+        keys[wave][m] = ((u64)__float_as_uint(dist_from_sim(c)) << 32) | (unsigned)tidx;
+    }
+    u64 prev1 = 0, mine = 0;
+    for (int r = 0; r < K; ++r) {
+        u64 best = ~0ull;
+        for (int m = lane; m < n; m += 64) {
+            const u64 kv = keys[wave][m];
+            if (kv + 1 > prev1 && kv < best) best = kv;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const u64 o = __shfl_xor(best, off);
+            best = o < best ? o : best;
+        }
+        prev1 = best + 1;
+        if (lane == r) mine = best;
+    }
+    if (lane < K) {
+        idx_out[(size_t)q * K + lane] = (int)(unsigned)(mine & 0xffffffffull);
+        dist_out[(size_t)q * K + lane] = __uint_as_float((unsigned)(mine >> 32));
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_half_queries_kernel(const _Float16 *__restrict__ Qh,
+                                                                  const float *__restrict__ theta_all,
+                                                                  const int *__restrict__ list, int first,
+                                                                  int count, int DP,
+                                                                  _Float16 *__restrict__ Qc,
+                                                                  float *__restrict__ theta_c,
+                                                                  int *__restrict__ cnt) {
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    const int q = list[first + i];
+    for (int c = threadIdx.x; c < DP; c += 256) Qc[(size_t)i * DP + c] = Qh[(size_t)q * DP + c];
+    if (threadIdx.x == 0) {
+        theta_c[i] = theta_all[q];
+        cnt[i] = 0;
     }
 }
 
@@ -1464,7 +1645,9 @@ static bool knn_prefilter_wanted(const fdr_ctx *ctx, int dp, int64_t nt, int k) 
 struct PrefilterLayout {
     int kp, chunk;
     size_t knn_bytes;  // region shared (in stream order) by the prefilter pass and the exact passes
-    size_t off_ht, off_hq, off_cand, off_counter, off_flagged, off_qc, off_qzc, off_idxc, off_distc, total;
+    size_t off_ht, off_hq, off_cand, off_counter, off_flagged, off_qc, off_qzc, off_idxc, off_distc;
+    size_t off_rlist, off_theta, off_hqc, off_thetac, off_cnt, off_rcand, total;  // range pass
+    int rchunk;
 };
 
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -1484,12 +1667,19 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.off_ht = o;       o += align256((size_t)nt * dp * 2);
     L.off_hq = o;       o += align256((size_t)nq * dp * 2);
     L.off_cand = o;     o += align256((size_t)nq * L.kp * 8);
-    L.off_counter = o;  o += 1024;  // [0] uncertified, [1] all-zero queries; zero answer idx at +256, dist at +512
+    L.off_counter = o;  o += 1024;  // [0] exact list, [1] all-zero queries, [2] range list; zero answer at +256 / +512
     L.off_flagged = o;  o += align256((size_t)nq * 4);
     L.off_qc = o;       o += align256((size_t)L.chunk * dp * 4);
     L.off_qzc = o;      o += align256((size_t)L.chunk);
     L.off_idxc = o;     o += align256((size_t)L.chunk * k * 4);
     L.off_distc = o;    o += align256((size_t)L.chunk * k * 4);
+    L.rchunk = (int)std::min<int64_t>(nq, 32768);  // range pass: queries per launch
+    L.off_rlist = o;    o += align256((size_t)nq * 4);
+    L.off_theta = o;    o += align256((size_t)nq * 4);
+    L.off_hqc = o;      o += align256((size_t)L.rchunk * dp * 2);
+    L.off_thetac = o;   o += align256((size_t)L.rchunk * 4);
+    L.off_cnt = o;      o += align256((size_t)L.rchunk * 4);
+    L.off_rcand = o;    o += align256((size_t)L.rchunk * RANGE_CAP * 4);
     L.total = o;
     return L;
 }
@@ -1628,22 +1818,59 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
                        (const u64 *)d_partial, p.nseg, (int)nq, p.nq_pad, kp, d_cand);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(d_counter, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(d_counter, 0, 16, st));
+    int *d_rlist = reinterpret_cast<int *>(ws + L.off_rlist);
+    float *d_theta = reinterpret_cast<float *>(ws + L.off_theta);
+    const bool use_range = !(getenv("FDR_KNN_RANGE") && atoi(getenv("FDR_KNN_RANGE")) == 0);  // dev knob
     const float margin = 2.0f * FDR_PREFILTER_EPS + 4.0e-7f;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
                        (const u64 *)d_cand, kp, k, d_Qhat, d_qzero, d_That, (int)nq, dp, (int)t_base, margin,
-                       d_idx, d_dist, d_counter, d_flagged);
+                       d_idx, d_dist, d_counter, d_flagged, use_range ? d_rlist : (int *)nullptr, d_theta);
     HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
 
-    // how many queries could not be certified / are all-zero?  (one 8-byte read-back; the passes below
-    // are sized from it)
-    int counts[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(counts, d_counter, 8, hipMemcpyDeviceToHost, st));
+    // how many queries could not be certified / are all-zero / need a range pass?  (one 12-byte
+    // read-back; the passes below are sized from it)
+    int counts[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(counts, d_counter, 12, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     int count = counts[0];
-    const int zcount = counts[1];
-    ctx->last_flagged = count;
+    const int zcount = counts[1], rcount = counts[2];
+    ctx->last_flagged = count + rcount;
+    if (rcount > 0) {  // plateau queries: collect {d~ <= theta} with a second fp16 pass, rank it exactly
+        if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
+        _Float16 *d_hqc = reinterpret_cast<_Float16 *>(ws + L.off_hqc);
+        float *d_thetac = reinterpret_cast<float *>(ws + L.off_thetac);
+        int *d_cnt = reinterpret_cast<int *>(ws + L.off_cnt);
+        int *d_rcand = reinterpret_cast<int *>(ws + L.off_rcand);
+        for (int first = 0; first < rcount; first += L.rchunk) {
+            const int c = std::min(L.rchunk, rcount - first);
+            hipLaunchKernelGGL(gather_half_queries_kernel, dim3((unsigned)c), dim3(256), 0, st,
+                               (const _Float16 *)d_hq, (const float *)d_theta, (const int *)d_rlist, first, c,
+                               dp, d_hqc, d_thetac, d_cnt);
+            HIP_TRY(hipGetLastError());
+            const KnnPlan rp = knn_plan(ctx, c, nt, d, 1, prefilter_shape(dp));  // (k = 1: ring-only LDS)
+            const size_t rlds = (size_t)2 * 32 * 256;
+#define FDR_LAUNCH_RANGE(DP_, WPS_)                                                                     \
+    hipLaunchKernelGGL((knn_range_kernel<DP_, 4, WPS_>), dim3((unsigned)rp.nqb, (unsigned)rp.nseg),        \
+                       dim3(256), rlds, st, (const _Float16 *)d_hqc, (const float *)d_thetac, c,          \
+                       (const _Float16 *)d_ht, (int)nt, (int)t_base, rp.segs, d_cnt, d_rcand)
+            if (dp == 128) FDR_LAUNCH_RANGE(128, 4);
+            else if (dp == 256) FDR_LAUNCH_RANGE(256, 2);
+            else FDR_LAUNCH_RANGE(512, 2);
+#undef FDR_LAUNCH_RANGE
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(knn_rerank_long_kernel, dim3((unsigned)((c + 3) / 4)), dim3(256), 0, st,
+                               (const int *)(d_rlist + first), c, (const int *)d_cnt, (const int *)d_rcand, k,
+                               d_Qhat, d_That, dp, (int)t_base, d_idx, d_dist, d_counter, d_flagged);
+            HIP_TRY(hipGetLastError());
+        }
+        if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
+        // ranges that overflowed were appended to the exact list: read its final length
+        HIP_TRY(hipMemcpyAsync(counts, d_counter, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        count = counts[0];
+    }
     if (zcount > 0) {  // all-zero queries share one closed-form answer
         int *d_zidx = d_counter + 64;
         float *d_zdist = reinterpret_cast<float *>(d_counter + 128);
