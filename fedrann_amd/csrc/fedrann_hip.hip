@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void pack_zero_bits_kernel(const unsigned char
 // every queued key that is still smaller than the list maximum replaces it and the two lanes of the
 // query rescan the list together.  Exactness: keys order by (dist, idx); a rejected candidate has
 // dist >= tau.dist and a larger index than every listed key, so it can never belong to the top-k.
-#define QCAP 4
+#define QCAP 4  // default entries per lane append queue (the kernels take the actual value, 2 or 4)
 #define FDR_MAX_SEG 48
 
 // Target segment boundaries (in rows, multiples of 32 except the last): segment s = [b[s], b[s+1]).
@@ -283,7 +283,7 @@ template <int NT, int QW>
 __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lists,
                                              u64 *__restrict__ queue, unsigned *__restrict__ shared,
                                              const int ql, const int K, const int tid, const int h,
-                                             const bool dbgc) {
+                                             const int qcap, const bool dbgc) {
     DBG_COUNT(2);
     const int cnt_me = st.qcnt;
     const int cnt_other = __shfl_xor(cnt_me, 32);
@@ -292,7 +292,7 @@ __device__ __noinline__ TopkState topk_flush(TopkState st, u64 *__restrict__ lis
         const int owner_cnt = (h == ph) ? cnt_me : cnt_other;
         const int owner_tid = (tid & ~32) | (ph << 5);
 #pragma unroll 1
-        for (int i = 0; i < QCAP; ++i) {
+        for (int i = 0; i < qcap; ++i) {
             const bool active = i < owner_cnt;
             if (!__any(active)) break;
             u64 key = KEY_INF;
@@ -340,7 +340,7 @@ template <int NT, int QW>
 __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64 *__restrict__ lists,
                                             u64 *__restrict__ queue, unsigned *__restrict__ shared,
                                             const int ql, const int K, const int tid, const int h,
-                                            int idx0, int nvalid, const bool dbgc) {
+                                            int idx0, int nvalid, const int qcap, const bool dbgc) {
     // this block is cold: keep its address / index arithmetic from being hoisted into the hot loop
     asm volatile("" : "+s"(idx0), "+s"(nvalid));
     unsigned todo = 0xffffu;
@@ -369,7 +369,7 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
                 asm volatile("" : "+v"(a));
                 const float dist = dist_from_sim(a);
                 if (((todo >> r) & 1u) && (dist < st.tau || (retry && dist == st.tau))) {
-                    if (st.qcnt < QCAP) {
+                    if (st.qcnt < qcap) {
                         queue[st.qcnt * NT + tid] =
                             ((u64)__float_as_uint(dist) << 32) | (unsigned)(idxh + (r & 3) + 8 * (r >> 2));
                         ++st.qcnt;
@@ -380,7 +380,7 @@ __device__ __forceinline__ void topk_append(const f32x16 acc, TopkState &st, u64
             }
         }
         if (!__any(ovf != 0u)) break;
-        st = topk_flush<NT, QW>(st, lists, queue, shared, ql, K, tid, h, dbgc);
+        st = topk_flush<NT, QW>(st, lists, queue, shared, ql, K, tid, h, qcap, dbgc);
         todo = ovf;
         retry = true;
     }
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
     const float *__restrict__ Qh, const unsigned char *__restrict__ qzero, int nq,
     const float *__restrict__ Th, const unsigned *__restrict__ tzbits, int nt, int t_base,
     SegBounds segs, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared,
-    int dbg) {
+    int qcap, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 64 * NW;              // threads per workgroup
     constexpr int QW = 32 * NQ * NW;         // queries per workgroup
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
                         continue;
                     }
                     if (__any(mx > st[s].cfloor))
-                        topk_append<NT, QW>(acc[s], st[s], lists, queues + s * QCAP * NT, (tau_shared + qslot[s]), ql[s],
-                                            K, tid, h, t_base + tile_row0, t_end - tile_row0, (dbg & 2) != 0);
+                        topk_append<NT, QW>(acc[s], st[s], lists, queues + s * qcap * NT, (tau_shared + qslot[s]), ql[s],
+                                            K, tid, h, t_base + tile_row0, t_end - tile_row0, qcap, (dbg & 2) != 0);
                     if ((t & 31) == 31 && !(dbg & 4)) {  // refresh the cross-segment bound now and then
                         st[s].tau = topk_share((tau_shared + qslot[s]), st[s].taukey, h, st[s].foreign);
                         st[s].cfloor = sim_floor(st[s].tau);
@@ -549,8 +549,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_tile_kernel(
 #pragma unroll
     for (int s = 0; s < NQ; ++s)
         if (__any(st[s].qcnt > 0))
-            st[s] = topk_flush<NT, QW>(st[s], lists, queues + s * QCAP * NT, (tau_shared + qslot[s]), ql[s], K, tid, h,
-                                       (dbg & 2) != 0);
+            st[s] = topk_flush<NT, QW>(st[s], lists, queues + s * qcap * NT, (tau_shared + qslot[s]), ql[s], K, tid, h,
+                                       qcap, (dbg & 2) != 0);
     __syncthreads();
     {
         u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * QW) * K;
@@ -685,7 +685,7 @@ template <int DP, int NW, int WPS, int U>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const _Float16 *__restrict__ Qh, int nq, const _Float16 *__restrict__ Th, int nt, int t_base,
     SegBounds segs, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared,
-    int dbg) {
+    int qcap, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 64 * NW;
     constexpr int QW = 32 * NW;
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
                             if (mx > 3.0e38f) st.tau = mx;
                         } else if (__any(mx > st.cfloor))
                             topk_append<NT, QW>(acc, st, lists, queues, shared, ql, K, tid, h,
-                                                t_base + tile_row0, t_end - tile_row0, false);
+                                                t_base + tile_row0, t_end - tile_row0, qcap, false);
                     }
                 }
             }
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
             __syncthreads();  // stage it+1 is complete (all waves' pieces) before anyone reads it
         }
     }
-    if (__any(st.qcnt > 0)) st = topk_flush<NT, QW>(st, lists, queues, shared, ql, K, tid, h, false);
+    if (__any(st.qcnt > 0)) st = topk_flush<NT, QW>(st, lists, queues, shared, ql, K, tid, h, qcap, false);
     __syncthreads();
     {
         u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * QW) * K;
@@ -1472,11 +1472,22 @@ static int prefilter_shape(int dp) {
     return FDR_SHAPE_PREFILTER + (dp == 256 ? 1 : 2);
 }
 
-static size_t knn_lds_bytes(const KnnShape &sh, int k) {
+static size_t knn_lds_bytes_q(const KnnShape &sh, int k, int qcap) {
     const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
     const size_t ring = sh.tps > 0 ? (size_t)sh.tps * 32 * 256 : (size_t)2 * 32 * 64 * 4;
-    return ring + (size_t)k * qw * 8 + (size_t)QCAP * sh.nq * nt * 8;
+    return ring + (size_t)k * qw * 8 + (size_t)qcap * sh.nq * nt * 8;
 }
+
+// Entries per lane append queue: 4, or 2 when that lets one more workgroup share the CU's LDS
+// (co-resident workgroups matter more than the flush rate).
+static int knn_qcap(const KnnShape &sh, int k) {
+    const size_t lds = 160 * 1024;
+    const int with4 = (int)(lds / knn_lds_bytes_q(sh, k, 4)), with2 = (int)(lds / knn_lds_bytes_q(sh, k, 2));
+    const int by_regs = std::max(1, (sh.wps * 4) / sh.nw);
+    return std::min(with2, by_regs) > std::min(with4, by_regs) ? 2 : QCAP;
+}
+
+static size_t knn_lds_bytes(const KnnShape &sh, int k) { return knn_lds_bytes_q(sh, k, knn_qcap(sh, k)); }
 
 static int knn_wg_per_cu(const KnnShape &sh, int k) {
     const int by_lds = (int)((size_t)160 * 1024 / knn_lds_bytes(sh, k));
@@ -1727,7 +1738,7 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
         hipLaunchKernelGGL((knn_tile_kernel<DP_, NQ_, NW_, WPS_>), grid, dim3(64 * NW_), lds, st, d_Qhat, \
                            d_qzero, (int)nq, d_That, d_bits, (int)nt, (int)t_base, p.segs, k,        \
-                           p.nq_pad, d_partial, d_shared, dbg);                                      \
+                           p.nq_pad, d_partial, d_shared, knn_qcap(sh, k), dbg);                     \
     } while (0)
     switch (p.shape) {
         case 0: FDR_LAUNCH_KNN(128, 1, 4, 3); break;
@@ -1804,7 +1815,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
         hipLaunchKernelGGL((knn_prefilter_kernel<DP_, 4, WPS_, U_>), dim3((unsigned)p.nqb, (unsigned)p.nseg), \
                            dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp,   \
-                           p.nq_pad, d_partial, d_shared, pdbg);                                        \
+                           p.nq_pad, d_partial, d_shared, knn_qcap(sh, kp), pdbg);                      \
     } while (0)
     if (dp == 128 && sh.tps == 2) FDR_LAUNCH_PRE(128, 3, 1);
     else if (dp == 128) FDR_LAUNCH_PRE(128, 3, 2);
