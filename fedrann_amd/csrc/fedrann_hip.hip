@@ -1456,8 +1456,8 @@ static const KnnShape kShapes[] = {
     {256, 1, 8, 2, 0},  // 256 queries/WG, <=256 VGPRs, 1 WG/CU
     {512, 1, 4, 1, 0},  // 128 queries/WG, one wave per SIMD: 512 registers per lane (256 of them queries)
     {128, 1, 4, 3, 4},  // fp16 prefilter, d <= 128: 128 queries/WG, 32 KB LDS ring
-    {256, 1, 4, 2, 4},  // fp16 prefilter, d <= 256
-    {512, 1, 4, 2, 4},  // fp16 prefilter, d <= 512 (128 VGPRs of queries)
+    {256, 1, 4, 2, 2},  // fp16 prefilter, d <= 256 (one-unit stages, 16 KB ring)
+    {512, 1, 4, 2, 2},  // fp16 prefilter, d <= 512 (128 VGPRs of queries)
     {128, 1, 4, 3, 2},  // fp16 prefilter, d <= 128, one-unit stages (16 KB ring): a third workgroup per CU
 };
 #define FDR_SHAPE_PREFILTER 5  // + 0 / 1 / 2 for d <= 128 / 256 / 512
@@ -1819,8 +1819,8 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     } while (0)
     if (dp == 128 && sh.tps == 2) FDR_LAUNCH_PRE(128, 3, 1);
     else if (dp == 128) FDR_LAUNCH_PRE(128, 3, 2);
-    else if (dp == 256) FDR_LAUNCH_PRE(256, 2, 2);
-    else FDR_LAUNCH_PRE(512, 2, 2);
+    else if (dp == 256) FDR_LAUNCH_PRE(256, 2, 1);
+    else FDR_LAUNCH_PRE(512, 2, 1);
 #undef FDR_LAUNCH_PRE
     HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
