@@ -1,0 +1,79 @@
+"""End-to-end drop-in check on the GPU: the fedrann command line (python -m fedrann_amd) from the
+reference's intermediates / from feature_matrix.npz to overlaps.tsv, byte-compared with the
+reference's writer applied to the oracle's results (config 1 of BASELINE.json: plumbing)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from fedrann_amd import __main__ as cli
+from fedrann_amd import feature_extraction as fx
+from fedrann_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_intermediates(tmp_path, s, names):
+    """The two files the reference leaves in out/temp with --keep-intermediates."""
+    L = s["n_features"] // 2
+    fasta = tmp_path / "fwd_kmer_library.fasta"
+    with open(fasta, "w") as f:
+        for c in s["counts"]:
+            f.write(">%d\nACGTACGTACGTACG\n" % int(c))
+    out_bin = tmp_path / "output.bin"
+    rng = np.random.default_rng(0)
+    with open(out_bin, "wb") as f:
+        f.write(struct.pack("<4sB3sQ", b"KMER", 1, b"\0\0\0", len(names)))
+        for i, n in enumerate(names):
+            idx = s["indices"][s["indptr"][i]:s["indptr"][i + 1]].astype(np.int64)
+            idx = idx[rng.permutation(idx.size)]  # kmer_searcher emits a hash-set order
+            nb = n.encode()
+            f.write(struct.pack("<H", len(nb)) + nb + struct.pack("<I", idx.size))
+            f.write(struct.pack("<%dQ" % idx.size, *idx.tolist()))
+    return str(out_bin), str(fasta), L
+
+
+@pytest.mark.parametrize("d,k", [(128, 20), (500, 50)])
+def test_cli_from_kmer_searcher_output(tmp_path, oracle, d, k):
+    s = synth(900, seed=5, m=80)  # one row per record; the CLI doubles them (fwd + mirrored strand)
+    names = ["read_%d/ccs" % i for i in range(900)]
+    out_bin, fasta, L = _write_intermediates(tmp_path, s, names)
+    out_dir = tmp_path / "out"
+    cli.main(["-o", str(out_dir), "-n", str(d), "--nndescent-n-neighbors", str(k),
+              "--kmer-searcher-output", out_bin, "--kmer-library", fasta, "--save-feature-matrix"])
+    got = open(out_dir / "overlaps.tsv", newline="").read()
+    # oracle pipeline: reference-style parse -> P -> E -> exact k-NN -> the reference's writer loop
+    o_names, o_strands, o_rows = oracle.parse_output_bin(out_bin, L)
+    P = oracle.precompute_matrix(s["counts"], d)
+    indptr, indices = oracle.rows_to_csr(o_rows)
+    E = oracle.embed(indptr, indices, P, 2 * L, d)
+    idx, dist = oracle.knn(E, k)
+    want = oracle.overlaps_tsv(idx, dist, o_names, o_strands)
+    assert got == want
+    assert os.path.exists(out_dir / "fedrann.log")
+    # the saved feature matrix is the doubled binary CSR in scipy's npz layout
+    ip, ix, F = fx.load_feature_matrix_npz(str(out_dir / "feature_matrix.npz"))
+    assert F == 2 * L and ip.size - 1 == 1800
+    for r in (0, 1, 777, 1799):
+        assert ix[ip[r]:ip[r + 1]].tolist() == sorted(o_rows[r])
+
+
+def test_cli_from_feature_matrix_npz(tmp_path, oracle):
+    s = synth(1500, seed=9, m=60, doubling=True)
+    npz = tmp_path / "feature_matrix.npz"
+    fx.save_feature_matrix_npz(str(npz), s["indptr"], s["indices"], s["n_features"])
+    counts = tmp_path / "counts.npy"
+    np.save(counts, s["counts"])
+    names = tmp_path / "names.txt"
+    with open(names, "w") as f:
+        for n, st in zip(s["names"], s["strands"]):
+            f.write("%s\t%d\n" % (n, st))
+    out_dir = tmp_path / "out"
+    cli.main(["-o", str(out_dir), "-n", "128", "--nndescent-n-neighbors", "20", "--feature-matrix", str(npz),
+              "--kmer-counts", str(counts), "--read-names", str(names)])
+    got = open(out_dir / "overlaps.tsv", newline="").read()
+    P = oracle.precompute_matrix(s["counts"], 128)
+    E = oracle.embed(s["indptr"], s["indices"], P, s["n_features"], 128)
+    idx, dist = oracle.knn(E, 20)
+    assert got == oracle.overlaps_tsv(idx, dist, s["names"], s["strands"])
