@@ -170,6 +170,7 @@ def main():
 
     elapsed, kernel_ms, kernel_cnt, out = timed_run(args.steps, args.warmup)
     uncertified = ctx.last_uncertified()
+    uniq_t, uniq_q = ctx.last_unique()  # rows actually searched (duplicate-row classes)
     used_prefilter = kernel_cnt["knn_prefilter"] > 0
 
     # the same workload in the other mode, separately timed (never part of `value`)
@@ -199,8 +200,9 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n * k * args.steps / elapsed
-        # roofline of the dominant kernel: all ordered (query, target) pairs of this rank, 2*d flop each
-        flops = 2.0 * nloc * n * d
+        # roofline of the dominant kernel: the ordered (unique query, unique target) pairs this rank
+        # actually evaluated, 2*d flop each (= all nloc * n pairs when the class layer did not engage)
+        flops = 2.0 * uniq_q * uniq_t * d
 
         def mfma_roofline(kms, prefilter):
             name, peak = ("knn_prefilter", MFMA_F16_PEAK_TFLOPS) if prefilter else ("knn_tile", MFMA_F32_PEAK_TFLOPS)
@@ -244,6 +246,7 @@ def main():
                                             "bytes per launch)" if traffic else None),
             "knn_mode": "prefilter" if used_prefilter else "exact",
             "uncertified_queries_last_step": uncertified if used_prefilter else None,
+            "unique_rows_searched": {"targets": uniq_t, "queries": uniq_q, "of_targets": n, "of_queries": nloc},
             "kernels_ms": kernel_ms,
             "embed_roofline": {"bound": "hbm", "achieved": embed_bytes / (kernel_ms["embed_csr"] * 1e-3) / 1e9
                                if kernel_ms["embed_csr"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -15,10 +15,11 @@ SYMBOLS = (
     "fdr_create", "fdr_destroy", "fdr_last_error", "fdr_device_info", "fdr_padded_dim",
     "fdr_projection_load", "fdr_embed", "fdr_knn", "fdr_embed_knn", "fdr_embed_dev",
     "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_timing", "fdr_timing_read",
-    "fdr_last_uncertified", "fdr_set_knn_mode",
+    "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_last_unique",
 )
 FDR_MAX_K = 64
-KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank")
+KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
+           "knn_dedup")
 FDR_MAX_DIM = 512
 
 
@@ -57,6 +58,7 @@ def load_library():
     L.fdr_knn_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, vp, sz, vp]
     L.fdr_last_uncertified.argtypes = [vp]
     L.fdr_set_knn_mode.argtypes = [vp, ctypes.c_int]
+    L.fdr_last_unique.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.fdr_timing.argtypes = [vp, ctypes.c_int]
     L.fdr_timing_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(ctypes.c_float)]
@@ -134,6 +136,12 @@ class Context:
         """mode: "auto" (default), "exact" or "prefilter" -- same results, see include/fedrann_hip.h."""
         code = {"auto": 0, "exact": 1, "prefilter": 2}[mode]
         self._check(self._L.fdr_set_knn_mode(self._h, code), "fdr_set_knn_mode")
+
+    def last_unique(self):
+        """(unique target rows, unique query rows) searched by the last k-NN call."""
+        a, b = ctypes.c_int(), ctypes.c_int()
+        self._check(self._L.fdr_last_unique(self._h, ctypes.byref(a), ctypes.byref(b)), "fdr_last_unique")
+        return int(a.value), int(b.value)
 
     def last_uncertified(self):
         """Prefilter mode: query rows of the last k-NN call that were searched by the exact kernel."""

@@ -8,6 +8,9 @@
 // Written for wave64 / MFMA / 160 KB LDS directly; there is no other backend.
 // ABI: include/fedrann_hip.h.  Design notes and rooflines: DESIGN.md.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cstdarg>
@@ -1175,6 +1178,209 @@ __global__ __launch_bounds__(256) void scatter_results_kernel(const int *__restr
 }
 
 // ------------------------------------------------------------------------------------------
+// Duplicate-row classes.
+//
+// Sparse embeddings repeat: rows with one non-zero component are all +-e_a after normalisation, all
+// zero rows are identical, overlapping reads often hit the same few projected features (4 M synthetic
+// reads: 61 % unique rows, classes of ~1400 rows).  Bitwise-identical rows have bitwise-identical
+// distances to everything, so the search runs over UNIQUE query rows x UNIQUE target rows and classes
+// are expanded afterwards.  If classes are ordered by (dist, smallest member index), the exact top-K
+// of the expanded set lies inside the members of the first K classes: an element outside them is
+// preceded by K class representatives.  So: k-NN over representatives (stored in ascending index
+// order, so the kernels' (dist, row) order is (dist, representative)), then per query take the first
+// K members of each of its K classes and keep the K smallest (dist, index).
+// Classes come from a 64-bit row hash, a stable radix sort (members stay in index order) and a
+// full-row comparison of sorted neighbours (a hash collision only splits a class: harmless).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+// 16 lanes per row: position-salted, order-independent combination
+__global__ __launch_bounds__(256) void hash_rows_kernel(const float *__restrict__ X, int n, int DP,
+                                                        u64 *__restrict__ hash, int *__restrict__ idx) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int row = t >> 4, sub = t & 15;
+    u64 h = 0;
+    if (row < n) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(X + (size_t)row * DP);
+        for (int i = sub; i < DP / 4; i += 16) {
+            const uint4 v = p[i];
+            h += mix64(((u64)v.x | ((u64)v.y << 32)) ^ (0x9e3779b97f4a7c15ull * (u64)(2 * i + 1)));
+            h += mix64(((u64)v.z | ((u64)v.w << 32)) ^ (0x9e3779b97f4a7c15ull * (u64)(2 * i + 2)));
+        }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) h += __shfl_xor(h, off);
+    if (row < n && sub == 0) {
+        hash[row] = mix64(h);
+        idx[row] = row;
+    }
+}
+
+// flag[p] = 1 if sorted position p starts a new class (hash differs or the rows differ)
+__global__ __launch_bounds__(256) void mark_class_starts_kernel(const float *__restrict__ X, int n, int DP,
+                                                                const u64 *__restrict__ hash_s,
+                                                                const int *__restrict__ idx_s,
+                                                                int *__restrict__ flag) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int f = 1;
+    if (p > 0 && hash_s[p] == hash_s[p - 1]) {
+        const uint4 *a = reinterpret_cast<const uint4 *>(X + (size_t)idx_s[p] * DP);
+        const uint4 *b = reinterpret_cast<const uint4 *>(X + (size_t)idx_s[p - 1] * DP);
+        bool same = true;
+        for (int i = 0; i < DP / 4 && same; ++i) {
+            const uint4 u = a[i], v = b[i];
+            same = u.x == v.x && u.y == v.y && u.z == v.z && u.w == v.w;
+        }
+        f = same ? 0 : 1;
+    }
+    flag[p] = f;
+}
+
+// cid = inclusive scan of flag.  Per sorted position: class of the row, class start, representative mark.
+__global__ __launch_bounds__(256) void class_tables_kernel(int n, const int *__restrict__ flag,
+                                                           const int *__restrict__ cid_incl,
+                                                           const int *__restrict__ idx_s,
+                                                           int *__restrict__ cls_of_row,
+                                                           int *__restrict__ class_start,
+                                                           int *__restrict__ isrep) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int c = cid_incl[p] - 1;
+    const int r = idx_s[p];
+    cls_of_row[r] = c;
+    isrep[r] = flag[p];  // the first member in (stable) sorted order is the smallest index of its class
+    if (flag[p]) class_start[c] = p;
+    if (p == n - 1) class_start[c + 1] = n;
+}
+
+// upos = inclusive scan of isrep over ROW order: representative r becomes unique row upos[r]-1
+// (unique rows are therefore in ascending representative order).  Also marks unique rows that have a
+// member among the query rows [q0, q0+nq).
+__global__ __launch_bounds__(256) void unique_tables_kernel(int n, const int *__restrict__ isrep,
+                                                            const int *__restrict__ upos,
+                                                            const int *__restrict__ cls_of_row,
+                                                            int *__restrict__ u_of_class,
+                                                            int *__restrict__ class_of_u) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n || !isrep[r]) return;
+    const int u = upos[r] - 1;
+    const int c = cls_of_row[r];
+    u_of_class[c] = u;
+    class_of_u[u] = c;
+}
+
+__global__ __launch_bounds__(256) void gather_unique_rows_kernel(const float *__restrict__ X,
+                                                                 const unsigned char *__restrict__ zero,
+                                                                 int n, int DP, const int *__restrict__ isrep,
+                                                                 const int *__restrict__ upos,
+                                                                 float *__restrict__ U,
+                                                                 unsigned char *__restrict__ uzero) {
+    const int t = blockIdx.x * 256 + threadIdx.x;  // 16 lanes per row
+    const int r = t >> 4, sub = t & 15;
+    if (r >= n || !isrep[r]) return;
+    const int u = upos[r] - 1;
+    const uint4 *src = reinterpret_cast<const uint4 *>(X + (size_t)r * DP);
+    uint4 *dst = reinterpret_cast<uint4 *>(U + (size_t)u * DP);
+    for (int i = sub; i < DP / 4; i += 16) dst[i] = src[i];
+    if (sub == 0) uzero[u] = zero[r];
+}
+
+// which unique rows are needed as queries: those with a member in [q0, q0+nq)
+__global__ __launch_bounds__(256) void mark_query_classes_kernel(int q0, int nq,
+                                                                 const int *__restrict__ cls_of_row,
+                                                                 const int *__restrict__ u_of_class,
+                                                                 int *__restrict__ uqflag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    uqflag[u_of_class[cls_of_row[q0 + i]]] = 1;  // (benign race: every writer stores 1)
+}
+
+// uqpos = inclusive scan of uqflag: unique row u is unique query uqpos[u]-1
+__global__ __launch_bounds__(256) void gather_unique_queries_kernel(const float *__restrict__ U,
+                                                                    const unsigned char *__restrict__ uzero,
+                                                                    int nu, int DP,
+                                                                    const int *__restrict__ uqflag,
+                                                                    const int *__restrict__ uqpos,
+                                                                    float *__restrict__ Q,
+                                                                    unsigned char *__restrict__ qz) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int u = t >> 4, sub = t & 15;
+    if (u >= nu || !uqflag[u]) return;
+    const int j = uqpos[u] - 1;
+    const uint4 *src = reinterpret_cast<const uint4 *>(U + (size_t)u * DP);
+    uint4 *dst = reinterpret_cast<uint4 *>(Q + (size_t)j * DP);
+    for (int i = sub; i < DP / 4; i += 16) dst[i] = src[i];
+    if (sub == 0) qz[j] = uzero[u];
+}
+
+// One wave per QUERY row: look up its class's unique-query result (K classes by (dist, representative)),
+// take the first K members of each class (ascending index) and keep the K smallest (dist, index).
+// Lane r < K owns class r of the list (the four dependent table look-ups run once, in parallel);
+// dynamic LDS = K * K keys (K * min(K, class size) <= K * K).
+__global__ __launch_bounds__(64) void expand_classes_kernel(
+    int q0, int nq, int K, int t_base, const int *__restrict__ cls_of_row,
+    const int *__restrict__ u_of_class, const int *__restrict__ uqpos, const int *__restrict__ idx_u,
+    const float *__restrict__ dist_u, const int *__restrict__ class_of_u,
+    const int *__restrict__ class_start, const int *__restrict__ idx_s, int *__restrict__ idx_out,
+    float *__restrict__ dist_out) {
+    extern __shared__ u64 keys[];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
+    if (i >= nq) return;
+    const int j = uqpos[u_of_class[cls_of_row[q0 + i]]] - 1;  // this query's unique-query number
+    int s0 = 0, m = 0;
+    unsigned db = 0;
+    if (lane < K) {
+        const int u = idx_u[(size_t)j * K + lane];
+        db = __float_as_uint(dist_u[(size_t)j * K + lane]);
+        const int c = class_of_u[u];
+        s0 = class_start[c];
+        m = min(K, class_start[c + 1] - s0);
+    }
+    int incl = m;  // inclusive prefix sum of m over the lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const int n = __shfl(incl, 63);
+    const int base = incl - m;
+    for (int r = 0; r < K; ++r) {
+        const int rs0 = __shfl(s0, r), rm = __shfl(m, r), rb = __shfl(base, r);
+        const unsigned rdb = (unsigned)__shfl((int)db, r);
+        if (lane < rm) keys[rb + lane] = ((u64)rdb << 32) | (unsigned)(t_base + idx_s[rs0 + lane]);
+    }
+    __syncthreads();
+    u64 prev1 = 0, mine = 0;
+    for (int r = 0; r < K; ++r) {
+        u64 best = ~0ull;
+        for (int e = lane; e < n; e += 64) {
+            const u64 kv = keys[e];
+            if (kv + 1 > prev1 && kv < best) best = kv;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const u64 o = __shfl_xor(best, off);
+            best = o < best ? o : best;
+        }
+        prev1 = best + 1;
+        if (lane == r) mine = best;
+    }
+    if (lane < K) {
+        idx_out[(size_t)i * K + lane] = (int)(unsigned)(mine & 0xffffffffull);
+        dist_out[(size_t)i * K + lane] = __uint_as_float((unsigned)(mine >> 32));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -1216,9 +1422,10 @@ struct fdr_ctx {
     // stream; fdr_timing_read() sums the elapsed times of all launches since the last read
     int knn_mode = FDR_MODE_AUTO;
     int last_flagged = 0;  // prefilter mode: queries of the last call that took the exact path
+    int last_unique_targets = 0, last_unique_queries = 0;  // duplicate-row classes of the last call
     bool timing = false;
     std::vector<hipEvent_t> ev_pool[FDR_NUM_KERNELS];  // start, stop, start, stop, ...
-    size_t ev_used[FDR_NUM_KERNELS] = {0, 0, 0, 0, 0, 0};
+    size_t ev_used[FDR_NUM_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 static int timing_begin(fdr_ctx *ctx, int kind, hipStream_t st) {
@@ -1299,6 +1506,13 @@ FDR_EXPORT int fdr_device_info(fdr_ctx *ctx, char *buf, int buflen) {
 }
 
 FDR_EXPORT int fdr_last_uncertified(fdr_ctx *ctx) { return ctx ? ctx->last_flagged : 0; }
+
+FDR_EXPORT int fdr_last_unique(fdr_ctx *ctx, int *unique_targets, int *unique_queries) {
+    if (!ctx || !unique_targets || !unique_queries) return fail(FDR_E_ARG, "bad argument");
+    *unique_targets = ctx->last_unique_targets;
+    *unique_queries = ctx->last_unique_queries;
+    return FDR_OK;
+}
 
 FDR_EXPORT int fdr_set_knn_mode(fdr_ctx *ctx, int mode) {
     if (!ctx || mode < FDR_MODE_AUTO || mode > FDR_MODE_PREFILTER) return fail(FDR_E_ARG, "bad k-NN mode");
@@ -1636,6 +1850,8 @@ static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int 
     return p;
 }
 
+static size_t knn_workspace_bytes_impl(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k);
+
 // ---- prefilter mode: workspace layout -------------------------------------------------------
 // mode: FDR_MODE_AUTO uses the fp16 prefilter whenever it applies (d <= 128, k + 8 <= 64) and the
 // target set is large enough to pay for it; FDR_KNN_MODE=exact|prefilter|auto overrides the context.
@@ -1698,8 +1914,7 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
 FDR_EXPORT size_t fdr_knn_workspace_bytes(fdr_ctx *ctx, int64_t nq, int64_t nt, int32_t d,
                                           int32_t k) {
     if (!ctx || nq <= 0 || nt <= 0 || k <= 0 || k > FDR_MAX_K || fdr_padded_dim(d) < 0) return 0;
-    if (knn_prefilter_wanted(ctx, fdr_padded_dim(d), nt, k)) return prefilter_layout(ctx, nq, nt, d, k).total;
-    return knn_plan(ctx, nq, nt, d, k).total_bytes;
+    return knn_workspace_bytes_impl(ctx, nq, nt, d, k);
 }
 
 static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
@@ -1912,9 +2127,14 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     return FDR_OK;
 }
 
-static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
-                      const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int d,
-                      int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes, hipStream_t st) {
+static size_t knn_mode_workspace_bytes(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
+    if (knn_prefilter_wanted(ctx, fdr_padded_dim(d), nt, k)) return prefilter_layout(ctx, nq, nt, d, k).total;
+    return knn_plan(ctx, nq, nt, d, k).total_bytes;
+}
+
+static int launch_knn_mode(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
+                           const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int d,
+                           int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes, hipStream_t st) {
     const int dp = fdr_padded_dim(d);
     if (dp > 0 && k >= 1 && k <= FDR_MAX_K && nq > 0 && nt >= k && knn_prefilter_wanted(ctx, dp, nt, k) &&
         d_Qhat && d_qzero && d_That && d_tzero && d_idx && d_dist && d_ws)
@@ -1922,6 +2142,152 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
                                     d_dist, d_ws, ws_bytes, st);
     return launch_knn_exact(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
                             d_ws, ws_bytes, st);
+}
+
+// ---- duplicate-row classes: search unique queries x unique targets, expand --------------------
+struct DedupLayout {
+    size_t inner_bytes;  // workspace of the inner k-NN call (sized for the un-deduplicated problem)
+    size_t off_hash, off_hash_s, off_idx, off_idx_s, off_flag, off_cid, off_cls, off_cstart, off_isrep,
+        off_upos, off_uofc, off_cofu, off_uqflag, off_uqpos, off_U, off_uzero, off_Uq, off_uqz, off_idxu,
+        off_distu, off_tmp, tmp_bytes, total;
+};
+
+static bool knn_dedup_wanted(int64_t nq, int64_t nt) {
+    if (const char *e = getenv("FDR_KNN_DEDUP")) return atoi(e) != 0;  // development knob
+    return nt >= 16384 && nq >= 1024;
+}
+
+static DedupLayout dedup_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
+    DedupLayout L;
+    const int dp = fdr_padded_dim(d);
+    L.inner_bytes = align256(knn_mode_workspace_bytes(ctx, nq, nt, d, k));
+    size_t o = L.inner_bytes;
+    auto take = [&](size_t bytes) { const size_t at = o; o += align256(bytes); return at; };
+    L.off_hash = take((size_t)nt * 8);
+    L.off_hash_s = take((size_t)nt * 8);
+    L.off_idx = take((size_t)nt * 4);
+    L.off_idx_s = take((size_t)nt * 4);
+    L.off_flag = take((size_t)nt * 4);
+    L.off_cid = take((size_t)nt * 4);
+    L.off_cls = take((size_t)nt * 4);
+    L.off_cstart = take((size_t)(nt + 1) * 4);
+    L.off_isrep = take((size_t)nt * 4);
+    L.off_upos = take((size_t)nt * 4);
+    L.off_uofc = take((size_t)nt * 4);
+    L.off_cofu = take((size_t)nt * 4);
+    L.off_uqflag = take((size_t)nt * 4);
+    L.off_uqpos = take((size_t)nt * 4);
+    L.off_U = take((size_t)nt * dp * 4);
+    L.off_uzero = take((size_t)nt);
+    L.off_Uq = take((size_t)nq * dp * 4);
+    L.off_uqz = take((size_t)nq);
+    L.off_idxu = take((size_t)nq * k * 4);
+    L.off_distu = take((size_t)nq * k * 4);
+    size_t t_sort = 0, t_scan = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, t_sort, (u64 *)nullptr, (u64 *)nullptr, (int *)nullptr,
+                                    (int *)nullptr, (size_t)nt, 0, 64, (hipStream_t) nullptr);
+    (void)rocprim::inclusive_scan(nullptr, t_scan, (int *)nullptr, (int *)nullptr, (size_t)nt,
+                                  rocprim::plus<int>(), (hipStream_t) nullptr);
+    L.tmp_bytes = align256(std::max(t_sort, t_scan));
+    L.off_tmp = take(L.tmp_bytes);
+    L.total = o;
+    return L;
+}
+
+static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
+                      const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int d,
+                      int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes, hipStream_t st) {
+    const int dp = fdr_padded_dim(d);
+    // the queries must be a block of the target rows (they are in every caller of this library)
+    const bool q_in_t = d_Qhat && d_That && dp > 0 && d_Qhat >= d_That &&
+                        d_Qhat + (size_t)nq * dp <= d_That + (size_t)nt * dp &&
+                        ((d_Qhat - d_That) % dp) == 0;
+    if (!(dp > 0 && k >= 1 && k <= FDR_MAX_K && nq > 0 && nt >= k && q_in_t && knn_dedup_wanted(nq, nt) &&
+          d_qzero && d_tzero && d_idx && d_dist && d_ws)) {
+        ctx->last_unique_targets = (int)nt;
+        ctx->last_unique_queries = (int)nq;
+        return launch_knn_mode(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
+                               d_ws, ws_bytes, st);
+    }
+    const DedupLayout L = dedup_layout(ctx, nq, nt, d, k);
+    if (ws_bytes < L.total) return fail(FDR_E_ARG, "knn: workspace %zu < required %zu bytes", ws_bytes, L.total);
+    char *ws = static_cast<char *>(d_ws);
+    u64 *hash = (u64 *)(ws + L.off_hash), *hash_s = (u64 *)(ws + L.off_hash_s);
+    int *idx = (int *)(ws + L.off_idx), *idx_s = (int *)(ws + L.off_idx_s), *flag = (int *)(ws + L.off_flag);
+    int *cid = (int *)(ws + L.off_cid), *cls = (int *)(ws + L.off_cls), *cstart = (int *)(ws + L.off_cstart);
+    int *isrep = (int *)(ws + L.off_isrep), *upos = (int *)(ws + L.off_upos), *uofc = (int *)(ws + L.off_uofc);
+    int *cofu = (int *)(ws + L.off_cofu), *uqflag = (int *)(ws + L.off_uqflag), *uqpos = (int *)(ws + L.off_uqpos);
+    float *U = (float *)(ws + L.off_U), *Uq = (float *)(ws + L.off_Uq);
+    uint8_t *uzero = (uint8_t *)(ws + L.off_uzero), *uqz = (uint8_t *)(ws + L.off_uqz);
+    int32_t *idx_u = (int32_t *)(ws + L.off_idxu);
+    float *dist_u = (float *)(ws + L.off_distu);
+    void *tmp = ws + L.off_tmp;
+    const int n = (int)nt;
+    const int q0 = (int)((d_Qhat - d_That) / dp);
+    const unsigned g16 = (unsigned)(((size_t)n * 16 + 255) / 256), g1 = (unsigned)((n + 255) / 256);
+
+    int trc = timing_begin(ctx, FDR_KERNEL_KNN_DEDUP, st);
+    if (trc) return trc;
+    hipLaunchKernelGGL(hash_rows_kernel, dim3(g16), dim3(256), 0, st, d_That, n, dp, hash, idx);
+    HIP_TRY(hipGetLastError());
+    size_t tb = L.tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, hash, hash_s, idx, idx_s, (size_t)n, 0, 64, st));
+    hipLaunchKernelGGL(mark_class_starts_kernel, dim3(g1), dim3(256), 0, st, d_That, n, dp,
+                       (const u64 *)hash_s, (const int *)idx_s, flag);
+    tb = L.tmp_bytes;
+    HIP_TRY(rocprim::inclusive_scan(tmp, tb, flag, cid, (size_t)n, rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(class_tables_kernel, dim3(g1), dim3(256), 0, st, n, (const int *)flag,
+                       (const int *)cid, (const int *)idx_s, cls, cstart, isrep);
+    tb = L.tmp_bytes;
+    HIP_TRY(rocprim::inclusive_scan(tmp, tb, isrep, upos, (size_t)n, rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(unique_tables_kernel, dim3(g1), dim3(256), 0, st, n, (const int *)isrep,
+                       (const int *)upos, (const int *)cls, uofc, cofu);
+    HIP_TRY(hipMemsetAsync(uqflag, 0, (size_t)n * 4, st));
+    hipLaunchKernelGGL(mark_query_classes_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, q0,
+                       (int)nq, (const int *)cls, (const int *)uofc, uqflag);
+    tb = L.tmp_bytes;
+    HIP_TRY(rocprim::inclusive_scan(tmp, tb, uqflag, uqpos, (size_t)n, rocprim::plus<int>(), st));
+    HIP_TRY(hipGetLastError());
+    int nu = 0, nuq = 0;
+    HIP_TRY(hipMemcpyAsync(&nu, cid + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&nuq, uqpos + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    ctx->last_unique_targets = nu;
+    ctx->last_unique_queries = nuq;
+    const char *knob = getenv("FDR_KNN_DEDUP");
+    const bool always = knob && atoi(knob) == 2;  // development knob: expand even without duplicates
+    const bool worth = nu >= k && (always || (double)nu * nuq <= 0.9 * (double)nt * (double)nq);
+    size_t inner_need = worth ? knn_mode_workspace_bytes(ctx, nuq, nu, d, k) : 0;
+    if (!worth || inner_need > L.inner_bytes) {  // few duplicates (or, never seen, no room): plain search
+        if ((trc = timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st))) return trc;
+        ctx->last_unique_targets = (int)nt;
+        ctx->last_unique_queries = (int)nq;
+        return launch_knn_mode(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
+                               d_ws, L.inner_bytes, st);
+    }
+    hipLaunchKernelGGL(gather_unique_rows_kernel, dim3(g16), dim3(256), 0, st, d_That, d_tzero, n, dp,
+                       (const int *)isrep, (const int *)upos, U, uzero);
+    hipLaunchKernelGGL(gather_unique_queries_kernel, dim3((unsigned)(((size_t)nu * 16 + 255) / 256)), dim3(256),
+                       0, st, (const float *)U, (const unsigned char *)uzero, nu, dp, (const int *)uqflag,
+                       (const int *)uqpos, Uq, uqz);
+    HIP_TRY(hipGetLastError());
+    if ((trc = timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st))) return trc;
+    // unique rows are stored in ascending representative order, and the unique queries are a subsequence
+    // of them; the inner search numbers targets 0..nu-1
+    int rc = launch_knn_mode(ctx, Uq, uqz, nuq, U, uzero, nu, 0, d, k, idx_u, dist_u, d_ws, L.inner_bytes, st);
+    if (rc) return rc;
+    if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_DEDUP, st))) return trc;
+    hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)nq), dim3(64), (size_t)k * k * 8, st, q0, (int)nq, k, (int)t_base,
+                       (const int *)cls, (const int *)uofc, (const int *)uqpos, (const int *)idx_u,
+                       (const float *)dist_u, (const int *)cofu, (const int *)cstart, (const int *)idx_s, d_idx,
+                       d_dist);
+    HIP_TRY(hipGetLastError());
+    return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
+}
+
+static size_t knn_workspace_bytes_impl(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
+    if (knn_dedup_wanted(nq, nt)) return dedup_layout(ctx, nq, nt, d, k).total;
+    return knn_mode_workspace_bytes(ctx, nq, nt, d, k);
 }
 
 // ---- device-pointer API ----------------------------------------------------------------------

@@ -112,7 +112,8 @@ int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64
 #define FDR_KERNEL_KNN_PREFILTER 4 /* fp16 MFMA candidate kernel of the prefilter mode */
 #define FDR_KERNEL_KNN_RERANK 5    /* rest of the prefilter mode: fp16 conversion, key merge, certificate +
                                       exact fp32 re-rank (two timed spans per call) */
-#define FDR_NUM_KERNELS 6
+#define FDR_KERNEL_KNN_DEDUP 6     /* duplicate-row classes: hash, sort, class tables, gathers, expansion */
+#define FDR_NUM_KERNELS 7
 int fdr_timing(fdr_ctx *ctx, int enable);
 int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out);
 /* ---- k-NN mode ---------------------------------------------------------------------------------
@@ -127,6 +128,9 @@ int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out
 #define FDR_MODE_EXACT 1
 #define FDR_MODE_PREFILTER 2
 int fdr_set_knn_mode(fdr_ctx *ctx, int mode);
+/* Duplicate-row classes: unique target / query rows the most recent k-NN call
+ * actually searched (= the row counts when the call found too few duplicates to bother). */
+int fdr_last_unique(fdr_ctx *ctx, int *unique_targets, int *unique_queries);
 /* Prefilter mode only: number of query rows of the most recent k-NN call whose candidate set could
  * not be certified and that were therefore searched by the exact kernel. */
 int fdr_last_uncertified(fdr_ctx *ctx);

@@ -12,12 +12,22 @@ from fedrann_amd.synth import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["exact", "prefilter"])
+@pytest.fixture(autouse=True, params=["exact", "prefilter", "exact+classes", "prefilter+classes"])
 def knn_mode(request, monkeypatch):
     """Every test runs under both k-NN modes.  "prefilter" = fp16 MFMA candidate pass + certificate +
-    exact fp32 re-rank (exact kernel for uncertified queries); its results must be the same bits."""
-    monkeypatch.setenv("FDR_KNN_MODE", request.param)
+    exact fp32 re-rank (exact kernel for uncertified queries); its results must be the same bits.
+    "+classes" forces the duplicate-row class layer (search unique rows, expand) at every size -- by
+    default it only engages from 16384 target rows, which the large tests below cover."""
+    mode, _, classes = request.param.partition("+")
+    monkeypatch.setenv("FDR_KNN_MODE", mode)
+    if classes:
+        monkeypatch.setenv("FDR_KNN_DEDUP", "2")
     return request.param
+
+
+def _skip_forced_classes(knn_mode):
+    if "+" in knn_mode:
+        pytest.skip("the class layer engages by itself at this size")
 
 
 def _bits(a):
@@ -142,9 +152,10 @@ def test_knn_synthetic_pipeline_config2_shape_small(ctx, oracle):
     _assert_knn_equal(ctx.knn(E, 20), (idx, dist))  # fused == separate
 
 
-def test_knn_full_size_properties_and_sampled_oracle(ctx, oracle):
+def test_knn_full_size_properties_and_sampled_oracle(ctx, oracle, knn_mode):
     """BASELINE config 2 (100k rows, d=128, k=20): size-independent properties over the whole
     result + exact oracle agreement on a sample of query rows."""
+    _skip_forced_classes(knn_mode)
     s = synth(100_000, seed=602)
     P = build_precompute_matrix(s["counts"], 128)
     ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], 128)
@@ -165,9 +176,11 @@ def test_knn_full_size_properties_and_sampled_oracle(ctx, oracle):
     _assert_knn_equal((idx[rows], dist[rows]), (wi, wd))
 
 
-def test_knn_one_million_rows_sampled_oracle(ctx, oracle):
+def test_knn_one_million_rows_sampled_oracle(ctx, oracle, knn_mode):
     """BASELINE config 3 (1M rows, d=128, k=20, ~6 non-zeros per embedding row => heavy ties, ~2 %
-    all-zero rows): exact oracle agreement on a sample of query rows + whole-result properties."""
+    all-zero rows, 17 % duplicate rows): exact oracle agreement on a sample of query rows +
+    whole-result properties."""
+    _skip_forced_classes(knn_mode)
     s = synth(1_000_000, seed=602)
     P = build_precompute_matrix(s["counts"], 128)
     ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], 128)
@@ -203,7 +216,7 @@ def test_knn_tight_clusters_all_ties(ctx, oracle):
 def test_prefilter_error_bound_and_fallback_accounting(ctx, oracle, knn_mode):
     """The certificate's eps must bound |fp16 similarity - fp32 chain| (checked on sampled pairs with
     numpy's fp16), and an input made of near-ties must be routed through the exact kernel."""
-    if knn_mode != "prefilter":
+    if not knn_mode.startswith("prefilter"):
         pytest.skip("prefilter mode only")
     rng = np.random.default_rng(12)
     E = rng.standard_normal((4000, 128)).astype(np.float32)
@@ -221,6 +234,55 @@ def test_prefilter_error_bound_and_fallback_accounting(ctx, oracle, knn_mode):
     T = base[rng.integers(0, 4, size=3000)] + 1e-4 * rng.standard_normal((3000, 128)).astype(np.float32)
     _assert_knn_equal(ctx.knn(T, 20), oracle.knn(T, 20))
     assert ctx.last_uncertified() > 0
+
+
+def _rows_with_duplicate_classes(rng, n, d, n_unique):
+    """Sparse rows drawn from n_unique distinct ones with very uneven multiplicities (classes of 1 up to
+    thousands, incl. the all-zero class and rows that differ only by a positive scale)."""
+    U = rng.standard_normal((n_unique, d)).astype(np.float32)
+    U[rng.random(U.shape) < 0.95] = 0
+    U[:40] = 0
+    U[40:48, :] = 0
+    U[40:48, 7] = 1.0  # eight "distinct" slots that are the same row
+    w = rng.pareto(0.7, size=n_unique) + 0.02
+    pick = rng.choice(n_unique, size=n, p=w / w.sum())
+    E = U[pick]
+    scale = np.where(rng.random(n) < 0.3, np.float32(2.0), np.float32(1.0))  # exact in fp32
+    return (E * scale[:, None]).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,d,k,n_unique", [(40_000, 128, 20, 5000), (30_000, 200, 50, 300),
+                                            (20_000, 128, 64, 400)])
+def test_knn_duplicate_row_classes(ctx, oracle, n, d, k, n_unique):
+    """Inputs dominated by duplicate rows: the class layer must return the same bits as the plain
+    all-pairs search (members of a class in ascending index order, lists cut in the middle of a class)."""
+    rng = np.random.default_rng(n + k)
+    E = _rows_with_duplicate_classes(rng, n, d, n_unique)
+    got = ctx.knn(E, k)
+    ut, uq = ctx.last_unique()
+    assert k <= ut < n // 2 and uq == ut  # the layer engaged (all rows are queries here)
+    _assert_knn_equal(got, oracle.knn(E, k))
+
+
+def test_device_api_query_subset_with_duplicate_classes(ctx, oracle):
+    """A rank's query block is a slice of the targets; its classes are a subset of the target classes."""
+    import torch
+    from fedrann_amd.distributed import HipEngine
+    dev = torch.device("cuda", 0)
+    n = 36_000
+    E = _rows_with_duplicate_classes(np.random.default_rng(77), n, 128, 2500)
+    eng = HipEngine(ctx, dev)
+    dE = torch.from_numpy(E).to(dev)
+    Ehat = torch.zeros((n, 128), dtype=torch.float32, device=dev)
+    zero = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    eng.normalize(dE, Ehat, zero)
+    wi, wd = oracle.knn(E, 20)
+    for lo, hi in ((0, n), (18_000, 27_000), (n - 4099, n), (1, 2050)):
+        idx, dst = eng.knn(Ehat[lo:hi], zero[lo:hi], hi - lo, Ehat, zero, n, 128, 20)
+        torch.cuda.synchronize(dev)
+        ut, uq = ctx.last_unique()
+        assert uq <= ut < n // 2 and uq < hi - lo
+        _assert_knn_equal((idx.cpu().numpy(), dst.cpu().numpy()), (wi[lo:hi], wd[lo:hi]))
 
 
 def test_device_api_query_subset_like_a_rank(ctx, oracle):
