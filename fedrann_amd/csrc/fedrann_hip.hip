@@ -244,8 +244,10 @@ struct SegBounds {
 #ifdef FDR_DEBUG_COUNTERS  // development build only: event counters read back with FDR_KNN_DEBUG=2
 __device__ unsigned long long g_dbg_counters[8];
 #define DBG_COUNT(i) do { if (dbgc && (threadIdx.x & 63) == 0) atomicAdd(&g_dbg_counters[i], 1ull); } while (0)
+#define DBG_ADD(i, n) do { if (dbgc && (threadIdx.x & 63) == 0) atomicAdd(&g_dbg_counters[i], (unsigned long long)(n)); } while (0)
 #else
 #define DBG_COUNT(i) do { (void)dbgc; } while (0)
+#define DBG_ADD(i, n) do { (void)dbgc; } while (0)
 #endif
 
 struct TopkState {
@@ -643,6 +645,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FDR_PREFILTER_EPS 0.00105f
 #define FDR_PREFILTER_EXTRA 8
 
+// Key layout of the prefilter pass (see RegList): ib index bits for the longest segment, the rest (at
+// most 20) for the quantised distance.  At least 13 distance bits, i.e. segments of at most 2^19 rows.
+#define FDR_PREFILTER_MAX_IB 19
+static int prefilter_index_bits(int max_segment_rows) {
+    int ib = 8;
+    while ((1ll << ib) < max_segment_rows) ++ib;
+    return ib;
+}
+// |approximate distance - canonical distance| of a prefilter candidate: fp16 operands + the key grid
+static float prefilter_eps(int ib) {
+    const int qbits = std::min(20, 32 - ib);
+    return FDR_PREFILTER_EPS + 0.5f / (float)((1u << qbits) - 2u) + 1.0e-6f;
+}
+
 static int prefilter_extra() {  // candidates kept beyond k (development knob FDR_KNN_EXTRA)
     if (const char *e = getenv("FDR_KNN_EXTRA")) {
         const int v = atoi(e);
@@ -679,48 +695,125 @@ __device__ __forceinline__ void wait_vmcnt() {  // s_waitcnt vmcnt(N) with a lit
     else static_assert(N == 0, "add the literal form for this count");
 }
 
-// NW waves, one 32-query set per wave (QW = 32*NW queries per workgroup).  The targets stream through
-// a two-stage LDS ring; a stage holds two "units" of 32 rows x 128 fp16 components (8 KB each):
-// U units per stage.  What matters most is how many workgroups share a CU (their MFMAs fill the waits
-// at each other's per-stage barriers): at d <= 128 one-unit stages (16 KB ring, three workgroups per CU)
-// beat two-unit stages (32 KB, two per CU) 5.5 ms to 7.7 ms; deeper rings of the same total size lost.
-template <int DP, int NW, int WPS, int U>
+// ---- P1 top-k state: 32-bit keys in sorted register lists ------------------------------------
+// key = qd << ib | row - segment start.  qd = QM1 - rint(clamp(sim, 0, 1) * QM1) is the approximate
+// distance on a grid of QM1 = 2^qbits - 2 steps (qbits = min(20, 32 - ib); ib = bits of the longest
+// segment, chosen per launch), so the order of keys is (quantised distance, row).  The grid adds
+// 0.5 / QM1 to the prefilter's error bound (see prefilter_eps()).  EMPTY = all ones is larger than any key.
+// The K' keys of a query live in REGISTERS: lane j holds LH of them and lane j + 32 the other LH, each
+// half sorted ascending (positions beyond K' are pinned to key 0 and skipped at write-out).  The
+// list's maximum is therefore max(v[LH-1], partner's v[LH-1]); inserting c means: the half that
+// holds the maximum drops it and takes c, one v_med3_u32 per element
+//     v'[e] = med3(v[e-1], c, v[e]),  v'[0] = min(v[0], c)
+// (inserting EMPTY changes nothing, which is how the other half and idle queries sit the round out).
+// A round costs ~LH + 12 VALU instructions for all 32 queries of the wave at once, no LDS and no scan.
+#define PK_EMPTY 0xffffffffu
+
+__device__ __forceinline__ unsigned partner32(unsigned x, int h) {  // value held by lane ^ 32
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return h ? r[0] : r[1];
+}
+
+template <int LH>
+struct RegList {
+    unsigned v[LH];
+    unsigned pmax;  // partner half's maximum
+};
+
+// one insertion round: every query takes the smaller of its two lanes' candidates (PK_EMPTY = none);
+// returns the candidate that was considered (the other lane's, if any, must be offered again)
+template <int LH>
+__device__ __forceinline__ unsigned reglist_round(RegList<LH> &L, unsigned cand, int h) {
+    const unsigned c = min(cand, partner32(cand, h));
+    const unsigned mymax = L.v[LH - 1];
+    const bool hold = mymax > L.pmax || (mymax == L.pmax && h == 0);
+    const unsigned ce = (hold && c < mymax) ? c : PK_EMPTY;  // (hold => mymax is the list maximum)
+#pragma unroll
+    for (int e = LH - 1; e >= 1; --e) L.v[e] = max(min(L.v[e - 1], ce), min(max(L.v[e - 1], ce), L.v[e]));
+    L.v[0] = min(L.v[0], ce);
+    L.pmax = partner32(L.v[LH - 1], h);
+    return c;
+}
+
+// NW waves with NQ 32-query sets each (QW = 32*NQ*NW queries per workgroup; the NQ accumulator chains
+// of a wave share every target fragment read from LDS).  The targets stream through a two-stage LDS
+// ring; a stage holds U "units" of 32 rows x 128 fp16 components (8 KB each).  LDS holds nothing else
+// (the top-k lists are in registers), so the workgroups per CU are set by the register budget (WPS
+// waves per SIMD).  Staging a unit costs each wave 8/NW LDS-DMA issues of ~100 cycles, the same order
+// as the 8 MFMAs (256 cycles) one query set spends on it: NQ = 2 halves that share.
+template <int DP, int NQ, int NW, int WPS, int U, int LH>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const _Float16 *__restrict__ Qh, int nq, const _Float16 *__restrict__ Th, int nt, int t_base,
     SegBounds segs, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared,
-    int qcap, int dbg) {
+    int ib, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NT = 64 * NW;
-    constexpr int QW = 32 * NW;
+    constexpr int QW = 32 * NQ * NW;
     constexpr int NCH = DP / 128;            // 128-component chunks (= units) per tile
     constexpr int UNIT_BYTES = 32 * 256;
     constexpr int STAGE_BYTES = U * UNIT_BYTES;  // U units per stage
     constexpr int SP = NCH >= U ? NCH / U : 1;  // stages per loop iteration (keeps chunk numbers static)
     constexpr int SLOTS = 16;
-    u64 *lists = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES);
-    u64 *queues = reinterpret_cast<u64 *>(smem + 2 * STAGE_BYTES + (size_t)K * QW * 8);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int ql = wave * 32 + j;
-    const int qg = blockIdx.x * QW + ql;
-    const int qrow = qg < nq ? qg : nq - 1;
-    unsigned *shared = tau_shared + qg;
+    const int ql0 = wave * 32 * NQ + j;               // query set n: ql0 + 32 n
+    const int qg0 = blockIdx.x * QW + ql0;
 
-    f16x8 b[NCH * 8];  // B fragments: chunk c, k-step s covers components 128c + 16s + 8h .. + 7
-    {
-        const f16x8 *qp = reinterpret_cast<const f16x8 *>(Qh + (size_t)qrow * DP);
+    f16x8 b[NQ][NCH * 8];  // B fragments: chunk c, k-step s covers components 128c + 16s + 8h .. + 7
 #pragma unroll
-        for (int i = 0; i < NCH * 8; ++i) b[i] = qp[2 * i + h];
+    for (int n = 0; n < NQ; ++n) {
+        const int qg = qg0 + 32 * n;
+        const f16x8 *qp = reinterpret_cast<const f16x8 *>(Qh + (size_t)(qg < nq ? qg : nq - 1) * DP);
+#pragma unroll
+        for (int i = 0; i < NCH * 8; ++i) b[n][i] = qp[2 * i + h];
     }
-    for (int i = tid; i < K * QW; i += NT) lists[i] = KEY_INF;
-    TopkState st;
-    st.taukey = KEY_INF;
-    st.taupos = 0;
-    st.qcnt = 0;
-    st.tau = topk_share(shared, KEY_INF, h, st.foreign);
-    st.cfloor = sim_floor(st.tau);
+    // quantisation grid and the lists
+    const int qbits = min(20, 32 - ib);
+    const unsigned QM1 = (1u << qbits) - 2u;
+    const float qscale = (float)QM1, qinv = 1.0f / qscale;
+    const int nlive = (K - h + 1) >> 1, dead = LH - nlive;  // live entries of this half
+    RegList<LH> L[NQ];
+    unsigned flim[NQ];  // cross-segment bound on qd (admits qd <= flim); QM1 + 1 = none
+    float cfloor[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+#pragma unroll
+        for (int e = 0; e < LH; ++e) L[n].v[e] = e < dead ? 0u : PK_EMPTY;
+        L[n].pmax = PK_EMPTY;
+    }
+    // bound exchange (see topk_share): publish the list maximum's qd once the list is full
+    auto share = [&](RegList<LH> &Ln, unsigned &fl, int n) {
+        unsigned *slot = tau_shared + qg0 + 32 * n;
+        const unsigned tk = max(Ln.v[LH - 1], Ln.pmax);
+        const unsigned mine = tk == PK_EMPTY ? 0x7F800000u : (tk >> ib);
+        unsigned seen = mine;
+        if (h == 0) {
+            const unsigned old = mine <= QM1
+                                     ? __hip_atomic_fetch_min(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = min(old, mine);
+        }
+        const unsigned ps = partner32(seen, h);
+        fl = min(h ? ps : seen, QM1 + 1);
+    };
+    // Similarity floor below which no row of a LATER tile can enter.  Rows arrive in ascending order, so
+    // a later row with the list maximum's qd has a larger key than the maximum: the own bound is strict
+    // (qd < maximum's qd) -- which is what keeps plateaus (e.g. an all-zero query, every similarity 0)
+    // on the fast path.  The cross-segment bound admits ties.
+    auto refloor = [&](const RegList<LH> &Ln, unsigned fl) -> float {
+        const unsigned tk = max(Ln.v[LH - 1], Ln.pmax);
+        const unsigned oq = tk >> ib;
+        const unsigned lim = tk == PK_EMPTY ? fl : min(oq - 1u, fl);  // (oq == 0: wraps, handled below)
+        float cf = lim >= QM1 ? -__builtin_inff() : ((float)(QM1 - lim) - 0.75f) * qinv;
+        if (tk != PK_EMPTY && oq == 0u) cf = __builtin_inff();
+        return cf;
+    };
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        share(L[n], flim[n], n);
+        cfloor[n] = refloor(L[n], flim[n]);
+    }
 
     const int t_begin = segs.b[blockIdx.y];
     const int t_end = min(nt, segs.b[blockIdx.y + 1]);
@@ -747,11 +840,44 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
         }
     };
     if (nstages > 0) issue_stage(0);
-    __syncthreads();  // (hipcc drains the DMA before the barrier; also publishes the list set-up)
+    __syncthreads();  // (hipcc drains the DMA before the barrier)
 
-    f32x16 acc;
+    // the rows of one finished tile against query set n's list (cold: most tiles have no candidate)
+    auto offer = [&](const f32x16 &a, const float (&g)[4], RegList<LH> &Ln, const unsigned fl, const float cf,
+                     int lrow, int nvalid) {
+        const bool dbgc = (dbg & 2) != 0;
+        DBG_COUNT(1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int q4 = 0; q4 < 4; ++q4) {
+            if (!__any(g[q4] > cf)) continue;
+            DBG_COUNT(2);
+#pragma unroll
+            for (int r = 4 * q4; r < 4 * q4 + 4; ++r) {
+                const int roff = (r & 3) + 8 * (r >> 2);
+                const bool pass = a[r] > cf && roff + 4 * h < nvalid;
+                if (!__any(pass)) continue;
+                unsigned cand = PK_EMPTY;
+                if (pass) {
+                    const float sc = fminf(fmaxf(a[r], 0.0f), 1.0f);
+                    const unsigned qd = QM1 - (unsigned)__builtin_rintf(sc * qscale);
+                    if (qd <= fl) cand = (qd << ib) | (unsigned)(lrow + roff);
+                }
+                DBG_COUNT(3);
+                const unsigned took = reglist_round<LH>(Ln, cand, h);
+                const bool again = cand != PK_EMPTY && cand != took;
+                if (__any(again)) {
+                    DBG_COUNT(4);
+                    (void)reglist_round<LH>(Ln, again ? cand : PK_EMPTY, h);
+                }
+            }
+        }
+    };
+
+    f32x16 acc[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     for (int it0 = 0; it0 < nstages; it0 += SP) {
 #pragma unroll
         for (int sp = 0; sp < SP; ++sp) {
@@ -759,8 +885,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
             if (it + 1 < nstages) issue_stage(it + 1);  // lands before the barrier below
 #pragma unroll
             for (int uu = 0; uu < U; ++uu) {
-                constexpr int dummy = 0;
-                (void)dummy;
                 const int v = U * sp + uu;         // unit number inside this loop iteration (static)
                 const int c = v % NCH;             // static chunk number
                 const int unit = U * it + uu;
@@ -768,43 +892,70 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
                     const int t = unit / NCH;
                     if (c == 0) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                        for (int n = 0; n < NQ; ++n)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
                     }
                     const f16x8 *sb = reinterpret_cast<const f16x8 *>(smem + (it & 1) * STAGE_BYTES +
                                                                       uu * UNIT_BYTES) + j * SLOTS;
                     const int sw = j & 15;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb[(2 * s + h) ^ sw], b[c * 8 + s], acc,
-                                                                     0, 0, 0);
-                    if (c == NCH - 1) {
-                        float mx = acc[0];
+                    for (int s = 0; s < 8; ++s) {
+                        const f16x8 a = sb[(2 * s + h) ^ sw];
 #pragma unroll
-                        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-                        const int tile_row0 = t_begin + t * 32;
-                        if (dbg & 1) {  // timing experiment: MFMA + fast path only
-                            if (mx > 3.0e38f) st.tau = mx;
-                        } else if (__any(mx > st.cfloor))
-                            topk_append<NT, QW>(acc, st, lists, queues, shared, ql, K, tid, h,
-                                                t_base + tile_row0, t_end - tile_row0, qcap, false);
+                        for (int n = 0; n < NQ; ++n)
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[n][c * 8 + s], acc[n], 0, 0, 0);
+                    }
+                    if (c == NCH - 1) {
+                        // acc[n][r] = similarity of query j of set n with tile row (r&3) + 8*(r>>2) + 4*h
+#pragma unroll
+                        for (int n = 0; n < NQ; ++n) {
+                            float g[4];
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4)
+                                g[q4] = fmaxf(fmaxf(acc[n][4 * q4], acc[n][4 * q4 + 1]),
+                                              fmaxf(acc[n][4 * q4 + 2], acc[n][4 * q4 + 3]));
+                            const float mx = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3]));
+                            const bool dbgc = (dbg & 2) != 0;
+                            DBG_COUNT(0);
+                            if (dbg & 1) {  // timing experiment: MFMA + fast path only
+                                if (mx > 3.0e38f) cfloor[n] = mx;
+                            } else if (__any(mx > cfloor[n])) {
+                                int lrow = t * 32 + 4 * h;  // row - segment start of this lane's first row
+                                int nvalid = t_end - (t_begin + t * 32);
+                                asm volatile("" : "+v"(lrow), "+s"(nvalid));  // keep the cold block's set-up cold
+                                offer(acc[n], g, L[n], flim[n], cfloor[n], lrow, nvalid);
+                                cfloor[n] = refloor(L[n], flim[n]);
+                            }
+                        }
                     }
                 }
             }
             if ((it & 15) == 15) {
-                st.tau = topk_share(shared, st.taukey, h, st.foreign);
-                st.cfloor = sim_floor(st.tau);
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    share(L[n], flim[n], n);
+                    cfloor[n] = refloor(L[n], flim[n]);
+                }
             }
             __syncthreads();  // stage it+1 is complete (all waves' pieces) before anyone reads it
         }
     }
-    if (__any(st.qcnt > 0)) st = topk_flush<NT, QW>(st, lists, queues, shared, ql, K, tid, h, qcap, false);
-    __syncthreads();
-    {
-        u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * QW) * K;
-        const int total = QW * K;
-        for (int i = tid; i < total; i += NT) {
-            const int q = i / K, e = i % K;
-            out[i] = lists[e * QW + q];
+    const unsigned imask = (1u << ib) - 1u;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * QW + ql0 + 32 * n) * K +
+                   (h ? (K + 1) >> 1 : 0);
+#pragma unroll
+        for (int e = 0; e < LH; ++e) {
+            if (e >= dead) {
+                const unsigned kv = L[n].v[e];
+                u64 o = KEY_INF;
+                if (kv != PK_EMPTY)
+                    o = ((u64)__float_as_uint((float)(kv >> ib) / qscale) << 32) |
+                        (unsigned)(t_base + t_begin + (int)(kv & imask));
+                out[e - dead] = o;
+            }
         }
     }
 }
@@ -1669,26 +1820,20 @@ static const KnnShape kShapes[] = {
     {128, 2, 4, 2, 0},  // 256 queries/WG, <=256 VGPRs, up to 2 WG/CU
     {256, 1, 8, 2, 0},  // 256 queries/WG, <=256 VGPRs, 1 WG/CU
     {512, 1, 4, 1, 0},  // 128 queries/WG, one wave per SIMD: 512 registers per lane (256 of them queries)
-    {128, 1, 4, 3, 4},  // fp16 prefilter, d <= 128: 128 queries/WG, 32 KB LDS ring
-    {256, 1, 4, 2, 2},  // fp16 prefilter, d <= 256 (one-unit stages, 16 KB ring)
-    {512, 1, 4, 2, 2},  // fp16 prefilter, d <= 512 (128 VGPRs of queries)
-    {128, 1, 4, 3, 2},  // fp16 prefilter, d <= 128, one-unit stages (16 KB ring): a third workgroup per CU
+    // fp16 prefilter (LDS = the ring only): 128 queries/WG, two-unit stages (32 KB ring).  One-unit
+    // stages (a barrier per 8 MFMAs) cost +25 % at d <= 128, three / four-unit stages lose workgroups per
+    // CU, two query sets per wave (NQ = 2, 192 VGPRs) lost 10-25 % to the lower occupancy.
+    {128, 1, 4, 4, 4},  // d <= 128: <= 128 VGPRs, 4 WG/CU
+    {256, 1, 4, 3, 4},  // d <= 256: <= 168 VGPRs, one tile per stage
+    {512, 1, 4, 2, 4},  // d <= 512: 128 VGPRs of queries, half a tile per stage
 };
 #define FDR_SHAPE_PREFILTER 5  // + 0 / 1 / 2 for d <= 128 / 256 / 512
-static int prefilter_shape(int dp) {
-    if (dp == 128) {
-        // one-unit stages (16 KB ring) leave room for a third workgroup per CU, which is what hides
-        // the waits at the per-stage barrier: 5.5 ms vs 7.7 ms at 100 k rows.  FDR_KNN_RING=2 selects
-        // the two-unit form (development knob).
-        const char *e = getenv("FDR_KNN_RING");
-        return (e && atoi(e) == 2) ? FDR_SHAPE_PREFILTER : FDR_SHAPE_PREFILTER + 3;
-    }
-    return FDR_SHAPE_PREFILTER + (dp == 256 ? 1 : 2);
-}
+static int prefilter_shape(int dp) { return FDR_SHAPE_PREFILTER + (dp == 128 ? 0 : dp == 256 ? 1 : 2); }
 
 static size_t knn_lds_bytes_q(const KnnShape &sh, int k, int qcap) {
     const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
-    const size_t ring = sh.tps > 0 ? (size_t)sh.tps * 32 * 256 : (size_t)2 * 32 * 64 * 4;
+    if (sh.tps > 0) return (size_t)sh.tps * 32 * 256;  // fp16 prefilter: the ring only (lists in registers)
+    const size_t ring = (size_t)2 * 32 * 64 * 4;
     return ring + (size_t)k * qw * 8 + (size_t)qcap * sh.nq * nt * 8;
 }
 
@@ -1794,11 +1939,21 @@ static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int 
     // long segments followed by shorter ones that fill the tail (guided self-scheduling), chosen by
     // simulating the dispatch.  Segments of one query block share their bound (topk_share), so the
     // extra segments cost little more than their fixed set-up (`ov`, in tiles).
-    const int slots = ctx->num_cus * std::max(1, knn_wg_per_cu(sh, k));
+    int slots = ctx->num_cus * std::max(1, knn_wg_per_cu(sh, k));
+    // fp16 prefilter: a fourth workgroup on a CU hides latency but shares the same MFMA / LDS pipes; the
+    // dispatch model that matched the measurements best counts three (100 k rows: 3.3 ms vs 3.9 ms)
+    if (sh.tps > 0) slots = std::min(slots, ctx->num_cus * 3);
+    if (const char *e = getenv("FDR_KNN_SLOTS")) slots = ctx->num_cus * std::max(1, atoi(e));  // development knob
     const int T = (int)((nt + 31) / 32);  // tiles
     double ov = sh.tps > 0 ? 96.0 : 16.0;  // fp16 tiles are 16x shorter: the fixed cost weighs more
     if (const char *e = getenv("FDR_KNN_OV")) ov = atof(e);  // development knob
-    std::vector<int> best{T};
+    // fp16 prefilter keys index rows inside a segment with at most FDR_PREFILTER_MAX_IB bits
+    const int cap_tiles = sh.tps > 0 ? (1 << FDR_PREFILTER_MAX_IB) / 32 : T;
+    std::vector<int> best;
+    {
+        const int c0 = (T + cap_tiles - 1) / cap_tiles, l0 = (T + c0 - 1) / c0;
+        for (int left = T; left > 0; left -= l0) best.push_back(std::min(left, l0));
+    }
     double best_cost = simulate_makespan(best, p.nqb, slots, ov);
     const int min_tiles = sh.tps > 0 ? 128 : 24;  // never cut segments shorter than 768 (4096) rows
     for (int cmain = 1; cmain <= 24; ++cmain)
@@ -1822,6 +1977,7 @@ static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int 
                     left -= t;
                 }
                 if ((int)segs.size() > FDR_MAX_SEG) continue;
+                if (*std::max_element(segs.begin(), segs.end()) > cap_tiles) continue;
                 const double cost = simulate_makespan(segs, p.nqb, slots, ov);
                 if (cost < best_cost * 0.999) {
                     best_cost = cost;
@@ -1865,7 +2021,7 @@ static bool knn_prefilter_wanted(const fdr_ctx *ctx, int dp, int64_t nt, int k) 
     if (mode == FDR_MODE_EXACT) return false;
     const int kp = (k + prefilter_extra() + 1) & ~1;
     if (!(kp <= FDR_MAX_K && nt >= kp)) return false;
-    if (knn_lds_bytes(kShapes[prefilter_shape(dp)], kp) > 160 * 1024) return false;
+    if (nt > (int64_t)FDR_MAX_SEG << FDR_PREFILTER_MAX_IB) return false;  // segments too long for the keys
     return mode == FDR_MODE_PREFILTER || nt >= 8192;
 }
 
@@ -2020,24 +2176,45 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                        d_tzero, (int)nt, d_bits, d_shared, p.nq_pad);
     HIP_TRY(hipGetLastError());
     const size_t lds = knn_lds_bytes(sh, kp);
-    if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn prefilter: k'=%d needs %zu B of LDS", kp, lds);
+    int max_seg = 1;
+    for (int i = 0; i < p.nseg; ++i) max_seg = std::max(max_seg, p.segs.b[i + 1] - p.segs.b[i]);
+    const int ib = prefilter_index_bits(max_seg);
+    if (ib > FDR_PREFILTER_MAX_IB) return fail(FDR_E_ARG, "knn prefilter: segment of %d rows", max_seg);
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     const int pdbg = getenv("FDR_KNN_DEBUG") ? atoi(getenv("FDR_KNN_DEBUG")) : 0;
-#define FDR_LAUNCH_PRE(DP_, WPS_, U_)                                                                   \
+#define FDR_LAUNCH_PRE2(DP_, NQ_, WPS_, U_, LH_)                                                        \
     do {                                                                                                \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter_kernel<DP_, 4, WPS_, U_>), \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL((knn_prefilter_kernel<DP_, 4, WPS_, U_>), dim3((unsigned)p.nqb, (unsigned)p.nseg), \
-                           dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp,   \
-                           p.nq_pad, d_partial, d_shared, knn_qcap(sh, kp), pdbg);                      \
+        HIP_TRY(hipFuncSetAttribute(                                                                    \
+            reinterpret_cast<const void *>(knn_prefilter_kernel<DP_, NQ_, 4, WPS_, U_, LH_>),           \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                     \
+        hipLaunchKernelGGL((knn_prefilter_kernel<DP_, NQ_, 4, WPS_, U_, LH_>),                          \
+                           dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(256), lds, st, d_hq, (int)nq,  \
+                           d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, d_shared, ib,   \
+                           pdbg);                                                                       \
     } while (0)
-    if (dp == 128 && sh.tps == 2) FDR_LAUNCH_PRE(128, 3, 1);
-    else if (dp == 128) FDR_LAUNCH_PRE(128, 3, 2);
-    else if (dp == 256) FDR_LAUNCH_PRE(256, 2, 1);
-    else FDR_LAUNCH_PRE(512, 2, 1);
+#define FDR_LAUNCH_PRE(DP_, NQ_, WPS_, U_)                                                              \
+    do {                                                                                                \
+        if (kp <= 32) FDR_LAUNCH_PRE2(DP_, NQ_, WPS_, U_, 16);                                          \
+        else FDR_LAUNCH_PRE2(DP_, NQ_, WPS_, U_, 32);                                                   \
+    } while (0)
+    if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 2);
+    else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 3, 2);
+    else FDR_LAUNCH_PRE(512, 1, 2, 2);
+#undef FDR_LAUNCH_PRE2
 #undef FDR_LAUNCH_PRE
     HIP_TRY(hipGetLastError());
+#ifdef FDR_DEBUG_COUNTERS
+    if (pdbg & 2) {
+        unsigned long long c[8];
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_dbg_counters), sizeof(c)));
+        fprintf(stderr, "[fdr debug] prefilter grid %d x %d  wave-tiles %llu  cold %llu  groups %llu  rounds %llu  "
+                        "second rounds %llu  candidates %llu\n", p.nqb, p.nseg, c[0], c[1], c[2], c[3], c[4], c[5]);
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_counters), z, sizeof(z)));
+    }
+#endif
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
 
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
@@ -2048,7 +2225,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     int *d_rlist = reinterpret_cast<int *>(ws + L.off_rlist);
     float *d_theta = reinterpret_cast<float *>(ws + L.off_theta);
     const bool use_range = !(getenv("FDR_KNN_RANGE") && atoi(getenv("FDR_KNN_RANGE")) == 0);  // dev knob
-    const float margin = 2.0f * FDR_PREFILTER_EPS + 4.0e-7f;
+    const float margin = 2.0f * prefilter_eps(ib) + 4.0e-7f;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
                        (const u64 *)d_cand, kp, k, d_Qhat, d_qzero, d_That, (int)nq, dp, (int)t_base, margin,
                        d_idx, d_dist, d_counter, d_flagged, use_range ? d_rlist : (int *)nullptr, d_theta);
