@@ -1,11 +1,10 @@
 #!/bin/bash
-# A/B of prefilter stage depth (FDR_KNN_RING) x planner slots per CU at d=256 / d=500, k=50
-for cfg in "256 50" "500 50"; do set -- $cfg; for r in 0 2; do for sl in 0 2 3; do
+# A/B of prefilter workgroup shapes (FDR_KNN_PSHAPE: 0 = 4 waves, 8 = 8 waves, 16 = 8 waves x 2 query sets)
+for cfg in "128 20" "256 50" "500 50"; do set -- $cfg; for r in 0 8 16; do for sl in 0 2; do
   if [ $sl = 0 ]; then unset FDR_KNN_SLOTS; else export FDR_KNN_SLOTS=$sl; fi
-  FDR_KNN_DEBUG=8 FDR_KNN_RING=$r python bench.py --dim $1 --knn $2 --steps 3 --warmup 1 --cpu-baseline-seconds 0 --no-compare > gpurun_out/ring_$r.json 2> gpurun_out/ring_$r.err
-  grep "fdr plan" gpurun_out/ring_$r.err | tail -1
+  FDR_KNN_PSHAPE=$r python bench.py --dim $1 --knn $2 --steps 3 --warmup 1 --cpu-baseline-seconds 0 --no-compare > gpurun_out/ring_$r.json 2> gpurun_out/ring_$r.err
   python - <<PY
 import json
-j=json.load(open("gpurun_out/ring_$r.json")); print("dim", $1, "ring", $r, "slots", $sl, j["value"], j["ms_per_step"], j["kernels_ms"]["knn_prefilter"], j["kernels_ms"]["knn_rerank"], j["uncertified_queries_last_step"])
+j=json.load(open("gpurun_out/ring_$r.json")); print("dim", $1, "pshape", $r, "slots", $sl, round(j["value"]/1e6,1), round(j["ms_per_step"],2), round(j["kernels_ms"]["knn_prefilter"],2), j["uncertified_queries_last_step"], j["config"]["self_check"])
 PY
 done; done; done

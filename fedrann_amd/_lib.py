@@ -30,6 +30,26 @@ class FedrannHipError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP / HSA runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so.7; if
+    libfedrann_hip.so were loaded first it would pull in /opt/rocm's copy, and torch (imported later,
+    e.g. by fedrann_amd.distributed) would start a second runtime that sees no GPU.  So map torch's copy
+    first -- located without importing torch -- and let the dynamic linker resolve our DT_NEEDED
+    libamdhip64.so.7 to it (same SONAME).  FEDRANN_HIP_SYSTEM_RUNTIME=1 keeps the system runtime."""
+    if os.environ.get("FEDRANN_HIP_SYSTEM_RUNTIME") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass  # no torch, or an unloadable copy: the system runtime is used
+
+
 def load_library():
     """dlopen libfedrann_hip.so and declare the prototypes.  Needs no GPU."""
     global _lib
@@ -39,6 +59,7 @@ def load_library():
         raise FedrannHipError(
             "%s is missing: build it with `python -m fedrann_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    _share_torch_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
     L.fdr_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]

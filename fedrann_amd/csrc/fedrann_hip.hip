@@ -9,6 +9,7 @@
 // ABI: include/fedrann_hip.h.  Design notes and rooflines: DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <type_traits>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -739,8 +740,12 @@ __device__ __forceinline__ unsigned reglist_round(RegList<LH> &L, unsigned cand,
 // of a wave share every target fragment read from LDS).  The targets stream through a two-stage LDS
 // ring; a stage holds U "units" of 32 rows x 128 fp16 components (8 KB each).  LDS holds nothing else
 // (the top-k lists are in registers), so the workgroups per CU are set by the register budget (WPS
-// waves per SIMD).  Staging a unit costs each wave 8/NW LDS-DMA issues of ~100 cycles, the same order
-// as the 8 MFMAs (256 cycles) one query set spends on it: NQ = 2 halves that share.
+// waves per SIMD).
+// The loop is bound by VALU ISSUE, not by the MFMA pipe: a tile's 8 MFMAs occupy the pipe for 256
+// cycles, and every vector instruction of the SIMD's waves costs 4 issue cycles beside them.  Hence:
+// integer max3 tree on the accumulator bits (10 instructions per tile, group maxima as by-products),
+// stage parity unrolled so that every ds_read address is a register + immediate, LDS-DMA sources as
+// 32-bit offsets advanced by a constant, the wave number in an SGPR.
 template <int DP, int NQ, int NW, int WPS, int U, int LH>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const _Float16 *__restrict__ Qh, int nq, const _Float16 *__restrict__ Th, int nt, int t_base,
@@ -751,11 +756,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     constexpr int NCH = DP / 128;            // 128-component chunks (= units) per tile
     constexpr int UNIT_BYTES = 32 * 256;
     constexpr int STAGE_BYTES = U * UNIT_BYTES;  // U units per stage
-    constexpr int SP = NCH >= U ? NCH / U : 1;  // stages per loop iteration (keeps chunk numbers static)
-    constexpr int SLOTS = 16;
+    constexpr int ROW_BYTES = DP * 2;
+    static_assert(NCH % U == 0 || U % NCH == 0, "a stage holds whole tiles or a tile spans whole stages");
+    static_assert(NCH <= 2 * U, "a tile spans at most two stages (the loop is unrolled by stage parity)");
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations stay in SGPRs
     const int j = lane & 31, h = lane >> 5;
     const int ql0 = wave * 32 * NQ + j;               // query set n: ql0 + 32 n
     const int qg0 = blockIdx.x * QW + ql0;
@@ -775,7 +782,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const int nlive = (K - h + 1) >> 1, dead = LH - nlive;  // live entries of this half
     RegList<LH> L[NQ];
     unsigned flim[NQ];  // cross-segment bound on qd (admits qd <= flim); QM1 + 1 = none
-    float cfloor[NQ];
+    int cthr[NQ];       // a similarity can enter only if its bit pattern, as a signed int, is >= cthr
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
 #pragma unroll
@@ -797,64 +804,101 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
         const unsigned ps = partner32(seen, h);
         fl = min(h ? ps : seen, QM1 + 1);
     };
-    // Similarity floor below which no row of a LATER tile can enter.  Rows arrive in ascending order, so
-    // a later row with the list maximum's qd has a larger key than the maximum: the own bound is strict
+    // Threshold below which no row of a LATER tile can enter.  Rows arrive in ascending order, so a
+    // later row with the list maximum's qd has a larger key than the maximum: the own bound is strict
     // (qd < maximum's qd) -- which is what keeps plateaus (e.g. an all-zero query, every similarity 0)
-    // on the fast path.  The cross-segment bound admits ties.
-    auto refloor = [&](const RegList<LH> &Ln, unsigned fl) -> float {
+    // on the fast path.  The cross-segment bound admits ties.  As a similarity the threshold is
+    // ((QM1 - lim) - 0.75) / QM1 > 0 (a quarter step below the rounding boundary of the last admitted
+    // grid value), or -inf (everything enters), or +inf (nothing does).  Positive floats order like
+    // their bit patterns and a negative similarity has a negative pattern, so the test is one signed
+    // integer compare: INT_MIN = everything, INT_MAX = nothing.
+    auto rethreshold = [&](const RegList<LH> &Ln, unsigned fl) -> int {
         const unsigned tk = max(Ln.v[LH - 1], Ln.pmax);
         const unsigned oq = tk >> ib;
         const unsigned lim = tk == PK_EMPTY ? fl : min(oq - 1u, fl);  // (oq == 0: wraps, handled below)
-        float cf = lim >= QM1 ? -__builtin_inff() : ((float)(QM1 - lim) - 0.75f) * qinv;
-        if (tk != PK_EMPTY && oq == 0u) cf = __builtin_inff();
-        return cf;
+        int th = lim >= QM1 ? (int)0x80000000u : __float_as_int(((float)(QM1 - lim) - 0.75f) * qinv) + 1;
+        if (tk != PK_EMPTY && oq == 0u) th = 0x7fffffff;
+        return th;
     };
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
         share(L[n], flim[n], n);
-        cfloor[n] = refloor(L[n], flim[n]);
+        cthr[n] = rethreshold(L[n], flim[n]);
     }
 
     const int t_begin = segs.b[blockIdx.y];
     const int t_end = min(nt, segs.b[blockIdx.y + 1]);
     const int ntiles = (t_end - t_begin + 31) >> 5;
     const int nunits = ntiles * NCH;
-    const int nstages = (nunits + U - 1) / U;  // (a multiple of SP)
+    const int nstages = (nunits + U - 1) / U;
 
-    constexpr int PPW = 8 * U / NW;  // 1 KiB LDS-DMA pieces per wave per stage
+    // LDS-DMA: piece p = wave + NW*u (1 KiB: unit p>>3 of the stage, rows 4*(p&7)..+3 of that unit,
+    // 16 lanes per row; the 16-byte slot a lane fetches is XOR-swizzled with the row).  Sources are
+    // 32-bit byte offsets from the segment's first row (segments are at most 2^19 rows of <= 1 KiB);
+    // rows past the segment end are clamped to its last row (and masked when the tile is scored).
+    constexpr int PPW = 8 * U / NW;  // pieces per wave per stage
     static_assert((8 * U) % NW == 0, "unsupported wave count");
-    auto issue_stage = [&](int it) {
-        unsigned char *dst = smem + (it & 1) * STAGE_BYTES;
+    const char *seg_base = reinterpret_cast<const char *>(Th + (size_t)t_begin * DP);
+    const unsigned last_row_off = (unsigned)(t_end - 1 - t_begin) * ROW_BYTES;
+    unsigned soff[PPW];  // this lane's source row (as a byte offset) for the stage issued next
+    unsigned scol[PPW];  // its byte offset inside the row
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+        const int piece = wave + NW * u;
+        const int row = 4 * (piece & 7) + (lane >> 4), pslot = lane & 15;
+        // unit piece>>3 of a stage: tile (piece>>3) / NCH of the stage (NCH <= U), chunk (piece>>3) % NCH
+        // (+ U per odd stage when a tile spans two stages)
+        scol[u] = (unsigned)((pslot ^ (row & 15)) * 16 + ((piece >> 3) % NCH) * 256);
+        soff[u] = (unsigned)(32 * ((piece >> 3) / NCH) + row) * ROW_BYTES;
+    }
+    auto issue_stage = [&](auto par_c) {  // par = parity of the stage being issued
+        constexpr int par = decltype(par_c)::value;
+        unsigned char *dst = smem + par * STAGE_BYTES;
 #pragma unroll
         for (int u = 0; u < PPW; ++u) {
-            const int piece = wave + NW * u;            // 0..15: unit piece>>3, rows 4*(piece&7)..+3
-            const int unit = U * it + (piece >> 3);
-            const int t = unit / NCH, c = unit % NCH;
-            const int row = 4 * (piece & 7) + (lane >> 4), pslot = lane & 15;
-            const int trow = min(t_begin + 32 * t + row, t_end - 1);
-            const _Float16 *src =
-                Th + (size_t)trow * DP + (size_t)(c * 128) + (size_t)((pslot ^ (row & 15)) * 8);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+            const int piece = wave + NW * u;
+            const unsigned off = min(soff[u], last_row_off) + scol[u] + (NCH > U ? par * U * 256 : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(seg_base + off),
                                              (__attribute__((address_space(3))) void *)(dst + piece * 1024),
                                              16, 0, 0);
+            if constexpr (NCH <= U) soff[u] += (unsigned)(32 * (U / NCH)) * ROW_BYTES;  // U / NCH tiles further
+            else if constexpr (par == 1) soff[u] += (unsigned)32 * ROW_BYTES;  // second half done: next tile
         }
     };
-    if (nstages > 0) issue_stage(0);
+    if (nstages > 0) issue_stage(std::integral_constant<int, 0>{});
     __syncthreads();  // (hipcc drains the DMA before the barrier)
 
+    // Candidates wait in a two-entry queue per lane (registers) and enter the lists in batches: late in a
+    // scan a tile offers ~1 candidate to ONE of the wave's 32 queries, and a round costs the same for 1
+    // query as for 32.  A flush drains the queues with at most four rounds.  Queued candidates are not
+    // reflected in the threshold: it is only looser for that, never wrong.
+    unsigned q0[NQ], q1[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) q0[n] = q1[n] = PK_EMPTY;
+    auto flush = [&](RegList<LH> &Ln, unsigned &a0, unsigned &a1) {
+        const bool dbgc = (dbg & 2) != 0;
+        while (__any(a0 != PK_EMPTY)) {
+            DBG_COUNT(4);
+            const unsigned took = reglist_round<LH>(Ln, a0, h);  // the smaller head of the query's two lanes
+            if (a0 == took) {
+                a0 = a1;
+                a1 = PK_EMPTY;
+            }
+        }
+    };
     // the rows of one finished tile against query set n's list (cold: most tiles have no candidate)
-    auto offer = [&](const f32x16 &a, const float (&g)[4], RegList<LH> &Ln, const unsigned fl, const float cf,
-                     int lrow, int nvalid) {
+    auto offer = [&](const f32x16 &a, const int (&g)[4], RegList<LH> &Ln, unsigned &a0, unsigned &a1,
+                     const unsigned fl, const int th, int lrow, int nvalid) {
         const bool dbgc = (dbg & 2) != 0;
         DBG_COUNT(1);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            if (!__any(g[q4] > cf)) continue;
+            if (!__any(g[q4] >= th)) continue;
             DBG_COUNT(2);
 #pragma unroll
             for (int r = 4 * q4; r < 4 * q4 + 4; ++r) {
                 const int roff = (r & 3) + 8 * (r >> 2);
-                const bool pass = a[r] > cf && roff + 4 * h < nvalid;
+                const bool pass = __float_as_int(a[r]) >= th && roff + 4 * h < nvalid;
                 if (!__any(pass)) continue;
                 unsigned cand = PK_EMPTY;
                 if (pass) {
@@ -863,87 +907,111 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
                     if (qd <= fl) cand = (qd << ib) | (unsigned)(lrow + roff);
                 }
                 DBG_COUNT(3);
-                const unsigned took = reglist_round<LH>(Ln, cand, h);
-                const bool again = cand != PK_EMPTY && cand != took;
-                if (__any(again)) {
-                    DBG_COUNT(4);
-                    (void)reglist_round<LH>(Ln, again ? cand : PK_EMPTY, h);
-                }
+                if (__any(cand != PK_EMPTY && a1 != PK_EMPTY)) flush(Ln, a0, a1);  // some lane's queue is full
+                a1 = (a0 != PK_EMPTY && a1 == PK_EMPTY) ? cand : a1;
+                a0 = a0 == PK_EMPTY ? cand : a0;
             }
         }
     };
+
+    // this lane's eight fragment addresses inside a unit (k-step s reads slot (2s + h) ^ (j & 15) of row j)
+    // (as LDS addresses, ring base included, so that a read is `ds_read_b128 v, fa offset:stage/unit`)
+    typedef const f16x8 __attribute__((address_space(3))) lds_f16x8;
+    const unsigned ring = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    unsigned fa[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+        fa[s8] = ring + (unsigned)(j * 256 + (((2 * s8 + h) ^ (j & 15)) * 16));
+        asm volatile("" : "+v"(fa[s8]));  // (opaque: otherwise hipcc re-derives it with a v_add per read)
+    }
 
     f32x16 acc[NQ];
 #pragma unroll
     for (int n = 0; n < NQ; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    for (int it0 = 0; it0 < nstages; it0 += SP) {
+
+    auto stage_body = [&](auto par_c, int it) {
+        constexpr int par = decltype(par_c)::value;
+        if (it + 1 < nstages) issue_stage(std::integral_constant<int, par ^ 1>{});  // lands before the barrier below
 #pragma unroll
-        for (int sp = 0; sp < SP; ++sp) {
-            const int it = it0 + sp;
-            if (it + 1 < nstages) issue_stage(it + 1);  // lands before the barrier below
+        for (int uu = 0; uu < U; ++uu) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int c = NCH <= U ? uu % NCH : (U * par + uu) % NCH;  // static chunk number
+            const int unit = U * it + uu;
+            if (unit < nunits) {  // wave-uniform
+                const int t = unit / NCH;
+                if (c == 0) {
 #pragma unroll
-            for (int uu = 0; uu < U; ++uu) {
-                const int v = U * sp + uu;         // unit number inside this loop iteration (static)
-                const int c = v % NCH;             // static chunk number
-                const int unit = U * it + uu;
-                if (unit < nunits) {               // wave-uniform
-                    const int t = unit / NCH;
-                    if (c == 0) {
+                    for (int n = 0; n < NQ; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+                }
+                if constexpr (WPS <= 2) {  // 256 registers: all eight fragments in flight (+5 % at d = 500)
+                    f16x8 a[8];
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8)
+                        a[s8] = *(lds_f16x8 *)(size_t)(fa[s8] + (unsigned)(par * STAGE_BYTES + uu * UNIT_BYTES));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8)
 #pragma unroll
                         for (int n = 0; n < NQ; ++n)
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s8], b[n][c * 8 + s8], acc[n], 0, 0, 0);
+                } else {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-                    }
-                    const f16x8 *sb = reinterpret_cast<const f16x8 *>(smem + (it & 1) * STAGE_BYTES +
-                                                                      uu * UNIT_BYTES) + j * SLOTS;
-                    const int sw = j & 15;
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        const f16x8 a = sb[(2 * s + h) ^ sw];
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        const f16x8 a = *(lds_f16x8 *)(size_t)(fa[s8] + (unsigned)(par * STAGE_BYTES + uu * UNIT_BYTES));
 #pragma unroll
                         for (int n = 0; n < NQ; ++n)
-                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[n][c * 8 + s], acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[n][c * 8 + s8], acc[n], 0, 0, 0);
                     }
-                    if (c == NCH - 1) {
-                        // acc[n][r] = similarity of query j of set n with tile row (r&3) + 8*(r>>2) + 4*h
+                }
+                if (c == NCH - 1) {
+                    // acc[n][r] = similarity of query j of set n with tile row (r&3) + 8*(r>>2) + 4*h
 #pragma unroll
-                        for (int n = 0; n < NQ; ++n) {
-                            float g[4];
+                    for (int n = 0; n < NQ; ++n) {
+                        int g[4];
 #pragma unroll
-                            for (int q4 = 0; q4 < 4; ++q4)
-                                g[q4] = fmaxf(fmaxf(acc[n][4 * q4], acc[n][4 * q4 + 1]),
-                                              fmaxf(acc[n][4 * q4 + 2], acc[n][4 * q4 + 3]));
-                            const float mx = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3]));
-                            const bool dbgc = (dbg & 2) != 0;
-                            DBG_COUNT(0);
-                            if (dbg & 1) {  // timing experiment: MFMA + fast path only
-                                if (mx > 3.0e38f) cfloor[n] = mx;
-                            } else if (__any(mx > cfloor[n])) {
-                                int lrow = t * 32 + 4 * h;  // row - segment start of this lane's first row
-                                int nvalid = t_end - (t_begin + t * 32);
-                                asm volatile("" : "+v"(lrow), "+s"(nvalid));  // keep the cold block's set-up cold
-                                offer(acc[n], g, L[n], flim[n], cfloor[n], lrow, nvalid);
-                                cfloor[n] = refloor(L[n], flim[n]);
-                            }
+                        for (int q4 = 0; q4 < 4; ++q4)
+                            g[q4] = max(max(max(__float_as_int(acc[n][4 * q4]), __float_as_int(acc[n][4 * q4 + 1])),
+                                            __float_as_int(acc[n][4 * q4 + 2])),
+                                        __float_as_int(acc[n][4 * q4 + 3]));
+                        const int mx = max(max(max(g[0], g[1]), g[2]), g[3]);
+                        const bool dbgc = (dbg & 2) != 0;
+                        DBG_COUNT(0);
+                        if (dbg & 1) {  // timing experiment: MFMA + fast path only
+                            if (mx == 0x7fffffff) cthr[n] = mx;
+                        } else if (__any(mx >= cthr[n])) {
+                            int lrow = t * 32 + 4 * h;  // row - segment start of this lane's first row
+                            int nvalid = t_end - (t_begin + t * 32);
+                            asm volatile("" : "+v"(lrow), "+s"(nvalid));  // keep the cold block's set-up cold
+                            offer(acc[n], g, L[n], q0[n], q1[n], flim[n], cthr[n], lrow, nvalid);
+                            cthr[n] = rethreshold(L[n], flim[n]);
                         }
                     }
                 }
             }
-            if ((it & 15) == 15) {
-#pragma unroll
-                for (int n = 0; n < NQ; ++n) {
-                    share(L[n], flim[n], n);
-                    cfloor[n] = refloor(L[n], flim[n]);
-                }
-            }
-            __syncthreads();  // stage it+1 is complete (all waves' pieces) before anyone reads it
         }
+        if ((it & 15) == 15) {
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                flush(L[n], q0[n], q1[n]);
+                share(L[n], flim[n], n);
+                cthr[n] = rethreshold(L[n], flim[n]);
+            }
+        }
+        __syncthreads();  // stage it+1 is complete (all waves' pieces) before anyone reads it
+    };
+    for (int it0 = 0; it0 < nstages; it0 += 2) {
+        stage_body(std::integral_constant<int, 0>{}, it0);
+        if (it0 + 1 < nstages) stage_body(std::integral_constant<int, 1>{}, it0 + 1);
     }
     const unsigned imask = (1u << ib) - 1u;
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
+        flush(L[n], q0[n], q1[n]);
         u64 *out = partial + ((size_t)blockIdx.y * nq_pad + (size_t)blockIdx.x * QW + ql0 + 32 * n) * K +
                    (h ? (K + 1) >> 1 : 0);
 #pragma unroll
@@ -1826,9 +1894,21 @@ static const KnnShape kShapes[] = {
     {128, 1, 4, 4, 4},  // d <= 128: <= 128 VGPRs, 4 WG/CU
     {256, 1, 4, 3, 4},  // d <= 256: <= 168 VGPRs, one tile per stage
     {512, 1, 4, 2, 4},  // d <= 512: 128 VGPRs of queries, half a tile per stage
+    {128, 1, 8, 4, 4},  // 8 waves: 256 queries/WG (half the staging traffic per query)
+    {256, 1, 8, 3, 4},
+    {512, 1, 8, 2, 4},
+    {128, 2, 8, 2, 4},  // 8 waves x 2 query sets: 512 queries/WG
 };
 #define FDR_SHAPE_PREFILTER 5  // + 0 / 1 / 2 for d <= 128 / 256 / 512
-static int prefilter_shape(int dp) { return FDR_SHAPE_PREFILTER + (dp == 128 ? 0 : dp == 256 ? 1 : 2); }
+static int range_shape(int dp) { return FDR_SHAPE_PREFILTER + (dp == 128 ? 0 : dp == 256 ? 1 : 2); }
+static int prefilter_shape(int dp) {
+    const int base = FDR_SHAPE_PREFILTER + (dp == 128 ? 0 : dp == 256 ? 1 : 2);
+    if (const char *e = getenv("FDR_KNN_PSHAPE")) {  // development knob: 8 = 8-wave form, 16 = 8 waves x 2 sets
+        if (atoi(e) == 8) return base + 3;
+        if (atoi(e) == 16 && dp == 128) return FDR_SHAPE_PREFILTER + 6;
+    }
+    return base;
+}
 
 static size_t knn_lds_bytes_q(const KnnShape &sh, int k, int qcap) {
     const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
@@ -2183,24 +2263,28 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     const int pdbg = getenv("FDR_KNN_DEBUG") ? atoi(getenv("FDR_KNN_DEBUG")) : 0;
-#define FDR_LAUNCH_PRE2(DP_, NQ_, WPS_, U_, LH_)                                                        \
+#define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_)                                                   \
     do {                                                                                                \
         HIP_TRY(hipFuncSetAttribute(                                                                    \
-            reinterpret_cast<const void *>(knn_prefilter_kernel<DP_, NQ_, 4, WPS_, U_, LH_>),           \
+            reinterpret_cast<const void *>(knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>),         \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                     \
-        hipLaunchKernelGGL((knn_prefilter_kernel<DP_, NQ_, 4, WPS_, U_, LH_>),                          \
-                           dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(256), lds, st, d_hq, (int)nq,  \
+        hipLaunchKernelGGL((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>),                        \
+                           dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(64 * NW_), lds, st, d_hq, (int)nq, \
                            d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, d_shared, ib,   \
                            pdbg);                                                                       \
     } while (0)
-#define FDR_LAUNCH_PRE(DP_, NQ_, WPS_, U_)                                                              \
+#define FDR_LAUNCH_PRE(DP_, NQ_, NW_, WPS_, U_)                                                         \
     do {                                                                                                \
-        if (kp <= 32) FDR_LAUNCH_PRE2(DP_, NQ_, WPS_, U_, 16);                                          \
-        else FDR_LAUNCH_PRE2(DP_, NQ_, WPS_, U_, 32);                                                   \
+        if (kp <= 32) FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 16);                                     \
+        else FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 32);                                              \
     } while (0)
-    if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 2);
-    else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 3, 2);
-    else FDR_LAUNCH_PRE(512, 1, 2, 2);
+    if (dp == 128 && sh.nw == 8 && sh.nq == 2) FDR_LAUNCH_PRE(128, 2, 8, 2, 2);
+    else if (dp == 128 && sh.nw == 8) FDR_LAUNCH_PRE(128, 1, 8, 4, 2);
+    else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
+    else if (dp == 256 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 3, 2);
+    else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
+    else if (sh.nw == 8) FDR_LAUNCH_PRE(512, 1, 8, 2, 2);
+    else FDR_LAUNCH_PRE(512, 1, 4, 2, 2);
 #undef FDR_LAUNCH_PRE2
 #undef FDR_LAUNCH_PRE
     HIP_TRY(hipGetLastError());
@@ -2252,7 +2336,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                                (const _Float16 *)d_hq, (const float *)d_theta, (const int *)d_rlist, first, c,
                                dp, d_hqc, d_thetac, d_cnt);
             HIP_TRY(hipGetLastError());
-            const KnnPlan rp = knn_plan(ctx, c, nt, d, 1, prefilter_shape(dp));  // (k = 1: ring-only LDS)
+            const KnnPlan rp = knn_plan(ctx, c, nt, d, 1, range_shape(dp));  // (k = 1: ring-only LDS)
             const size_t rlds = (size_t)2 * 32 * 256;
 #define FDR_LAUNCH_RANGE(DP_, WPS_)                                                                     \
     hipLaunchKernelGGL((knn_range_kernel<DP_, 4, WPS_>), dim3((unsigned)rp.nqb, (unsigned)rp.nseg),        \
