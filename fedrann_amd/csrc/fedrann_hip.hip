@@ -1028,15 +1028,80 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     }
 }
 
-// P1's merge: like knn_merge_kernel but writes the KP sorted keys themselves
+// Ascending bitonic sort of one u64 key per lane across the wave (21 compare-exchange stages).
+__device__ __forceinline__ u64 wave_sort64(u64 key, const int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const u64 other = __shfl_xor(key, j);
+            const bool up = k == 64 || (lane & k) == 0;
+            const bool take_min = ((lane & j) == 0) == up;
+            key = (take_min == (other < key)) ? other : key;
+        }
+    }
+    return key;
+}
+
+// P1's merge: the KP smallest keys of a query's nseg segment lists, sorted.  One wave per query.
+// A segment list arrives as two ascending halves ([0, ceil(KP/2)) and the rest; KEY_INF = empty slot),
+// so a full list's maximum is the larger of the two last entries, and the smallest such maximum over
+// the segments bounds the query's KP-th key: usually little more than KP keys survive that bound, they
+// are compacted into LDS and sorted with one 64-lane bitonic network.  More than 64 survivors (wide
+// plateaus), or no full list: KP rounds of a wave-wide minimum over all keys.
 __global__ __launch_bounds__(256) void knn_merge_keys_kernel(const u64 *__restrict__ partial, int nseg,
                                                              int nq, int nq_pad, int KP,
                                                              u64 *__restrict__ cand) {
     __shared__ u64 stage[4][MERGE_CAP];
+    __shared__ u64 surv[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wave;
     if (q >= nq) return;
     const int M = nseg * KP;
+    {
+        // (the first eight segments' keys and the bound's operands are all in flight together)
+        u64 kvs[8];
+        auto load_batch = [&](int sg0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                kvs[i] = (lane < KP && sg0 + i < nseg) ? partial[((size_t)(sg0 + i) * nq_pad + q) * KP + lane]
+                                                       : KEY_INF;
+        };
+        load_batch(0);
+        u64 bound = KEY_INF;
+        if (lane < nseg) {
+            const u64 *l = partial + ((size_t)lane * nq_pad + q) * KP;
+            const u64 a = l[((KP + 1) >> 1) - 1], b2 = l[KP - 1];
+            if (a != KEY_INF && b2 != KEY_INF) bound = a > b2 ? a : b2;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const u64 o = __shfl_xor(bound, off);
+            bound = o < bound ? o : bound;
+        }
+        int total = 0;
+        if (bound != KEY_INF) {
+            for (int sg0 = 0;;) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u64 kv = kvs[i];
+                    const bool keep = kv <= bound;  // (bound < KEY_INF)
+                    const u64 mask = __ballot(keep);
+                    const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (keep && pos < 64) surv[wave][pos] = kv;
+                    total += __popcll(mask);
+                }
+                sg0 += 8;
+                if (sg0 >= nseg) break;
+                load_batch(sg0);
+            }
+        }
+        if (bound != KEY_INF && total <= 64) {  // (total >= KP: the bounding list alone has KP such keys)
+            const u64 kv = wave_sort64(lane < total ? surv[wave][lane] : KEY_INF, lane);
+            if (lane < KP) cand[(size_t)q * KP + lane] = kv;
+            return;
+        }
+    }
     const bool staged = M <= MERGE_CAP;
     u64 *mine_lds = stage[wave];
     if (staged)
@@ -1104,30 +1169,29 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
         const f32x4 *qp = reinterpret_cast<const f32x4 *>(Qhat + (size_t)q * DP);
         const f32x4 *tp = reinterpret_cast<const f32x4 *>(That + (size_t)(tidx - t_base) * DP);
         float c = 0.0f;
-        for (int g = 0; g < DP / 8; ++g) {  // canonical chain: components 8g .. 8g+7 in ascending order
-            const f32x4 qe = qp[2 * g], qo = qp[2 * g + 1], te = tp[2 * g], to = tp[2 * g + 1];
-            c = __builtin_fmaf(qe.x, te.x, c);
-            c = __builtin_fmaf(qo.x, to.x, c);
-            c = __builtin_fmaf(qe.y, te.y, c);
-            c = __builtin_fmaf(qo.y, to.y, c);
-            c = __builtin_fmaf(qe.z, te.z, c);
-            c = __builtin_fmaf(qo.z, to.z, c);
-            c = __builtin_fmaf(qe.w, te.w, c);
-            c = __builtin_fmaf(qo.w, to.w, c);
+        for (int g0 = 0; g0 < DP / 8; g0 += 8) {  // (DP is a multiple of 128: 8 groups = 16 loads in flight)
+            f32x4 te[8], to[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                te[i] = tp[2 * (g0 + i)];
+                to[i] = tp[2 * (g0 + i) + 1];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {  // canonical chain: components 8g .. 8g+7 in ascending order
+                const f32x4 qe = qp[2 * (g0 + i)], qo = qp[2 * (g0 + i) + 1];
+                c = __builtin_fmaf(qe.x, te[i].x, c);
+                c = __builtin_fmaf(qo.x, to[i].x, c);
+                c = __builtin_fmaf(qe.y, te[i].y, c);
+                c = __builtin_fmaf(qo.y, to[i].y, c);
+                c = __builtin_fmaf(qe.z, te[i].z, c);
+                c = __builtin_fmaf(qo.z, to[i].z, c);
+                c = __builtin_fmaf(qe.w, te[i].w, c);
+                c = __builtin_fmaf(qo.w, to[i].w, c);
+            }
         }
         exact = ((u64)__float_as_uint(dist_from_sim(c)) << 32) | (unsigned)tidx;
     }
-    u64 prev1 = 0, mine = 0;
-    for (int r = 0; r < K; ++r) {
-        u64 best = (exact + 1 > prev1) ? exact : ~0ull;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const u64 o = __shfl_xor(best, off);
-            best = o < best ? o : best;
-        }
-        prev1 = best + 1;
-        if (lane == r) mine = best;
-    }
+    const u64 mine = wave_sort64(exact, lane);  // (distinct targets: no equal keys; unused lanes sort last)
     if (lane < K) {
         idx_out[(size_t)q * K + lane] = (int)(unsigned)(mine & 0xffffffffull);
         dist_out[(size_t)q * K + lane] = __uint_as_float((unsigned)(mine >> 32));
@@ -1311,41 +1375,49 @@ __global__ __launch_bounds__(256) void gather_half_queries_kernel(const _Float16
 // The neighbours of an all-zero query do not depend on the query: the all-zero targets at distance 0
 // in index order, then every other target at distance 1 in index order.  One workgroup scans the
 // zero flags for the first K rows of each kind (stops as soon as K zero rows are known).
-__global__ __launch_bounds__(1024) void zero_answer_kernel(const unsigned char *__restrict__ tzero, int nt,
+__global__ __launch_bounds__(1024) void zero_answer_kernel(const unsigned *__restrict__ tzbits, int nt,
                                                            int t_base, int K, int *__restrict__ zidx,
                                                            float *__restrict__ zdist) {
     __shared__ int wz[16], wnz[16];
     __shared__ int zlist[FDR_MAX_K], nzlist[FDR_MAX_K];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwords = (nt + 31) >> 5;
     int zc = 0, nzc = 0;  // found so far (uniform)
-    for (int base = 0; base < nt && zc < K; base += 1024) {
-        const int row = base + tid;
-        const bool in = row < nt;
-        const bool z = in && tzero[row] != 0, nz = in && !z;
-        const u64 bz = __ballot(z), bnz = __ballot(nz);
-        if (lane == 0) {
-            wz[wave] = __popcll(bz);
-            wnz[wave] = __popcll(bnz);
+    for (int base = 0; base < nwords && zc < K; base += 1024) {  // 32768 rows per pass
+        const int w = base + tid;
+        unsigned zb = 0, nzb = 0;
+        if (w < nwords) {
+            const int rows = min(32, nt - 32 * w);
+            const unsigned valid = rows == 32 ? ~0u : (1u << rows) - 1u;
+            zb = tzbits[w] & valid;
+            nzb = valid & ~zb;
+        }
+        const int z = __popc(zb), nz = __popc(nzb);
+        int sz = z, snz = nz;  // inclusive scans over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int a = __shfl_up(sz, off), c = __shfl_up(snz, off);
+            if (lane >= off) {
+                sz += a;
+                snz += c;
+            }
+        }
+        if (lane == 63) {
+            wz[wave] = sz;
+            wnz[wave] = snz;
         }
         __syncthreads();
-        int pz = zc, pnz = nzc, tz = 0, tnz = 0;
-        for (int w = 0; w < 16; ++w) {
-            if (w < wave) {
-                pz += wz[w];
-                pnz += wnz[w];
+        int pz = zc + sz - z, pnz = nzc + snz - nz, tz = 0, tnz = 0;
+        for (int w2 = 0; w2 < 16; ++w2) {
+            if (w2 < wave) {
+                pz += wz[w2];
+                pnz += wnz[w2];
             }
-            tz += wz[w];
-            tnz += wnz[w];
+            tz += wz[w2];
+            tnz += wnz[w2];
         }
-        const u64 below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-        if (z) {
-            const int pos = pz + __popcll(bz & below);
-            if (pos < K) zlist[pos] = row;
-        }
-        if (nz) {
-            const int pos = pnz + __popcll(bnz & below);
-            if (pos < K) nzlist[pos] = row;
-        }
+        for (unsigned m = zb; m && pz < K; m &= m - 1) zlist[pz++] = 32 * w + __ffs(m) - 1;
+        for (unsigned m = nzb; m && pnz < K; m &= m - 1) nzlist[pnz++] = 32 * w + __ffs(m) - 1;
         zc += tz;
         nzc += tnz;
         __syncthreads();
@@ -1358,15 +1430,19 @@ __global__ __launch_bounds__(1024) void zero_answer_kernel(const unsigned char *
     }
 }
 
+// (launched before the host knows how many all-zero queries there are: the count is read on the device;
+// they are the last counter[1] entries of `flagged`, which has nq slots)
 __global__ __launch_bounds__(256) void scatter_zero_answer_kernel(const int *__restrict__ zidx,
                                                                   const float *__restrict__ zdist,
-                                                                  const int *__restrict__ list, int count,
-                                                                  int K, int *__restrict__ idx_out,
+                                                                  const int *__restrict__ flagged, int nq,
+                                                                  const int *__restrict__ counter, int K,
+                                                                  int *__restrict__ idx_out,
                                                                   float *__restrict__ dist_out) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= count * K) return;
-    const int i = t / K, e = t - i * K;
-    const int q = list[i];
+    const int count = counter[1];
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)count * K) return;
+    const int i = (int)(t / K), e = (int)(t - (long long)i * K);
+    const int q = flagged[nq - count + i];
     idx_out[(size_t)q * K + e] = zidx[e];
     dist_out[(size_t)q * K + e] = zdist[e];
 }
@@ -2264,10 +2340,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     const int pdbg = getenv("FDR_KNN_DEBUG") ? atoi(getenv("FDR_KNN_DEBUG")) : 0;
 #define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_)                                                   \
-    do {                                                                                                \
-        HIP_TRY(hipFuncSetAttribute(                                                                    \
-            reinterpret_cast<const void *>(knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>),         \
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                     \
+    do { /* (the ring is at most 32 KB: no dynamic-LDS attribute needed) */                             \
         hipLaunchKernelGGL((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>),                        \
                            dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(64 * NW_), lds, st, d_hq, (int)nq, \
                            d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, d_shared, ib,   \
@@ -2313,6 +2386,15 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
                        (const u64 *)d_cand, kp, k, d_Qhat, d_qzero, d_That, (int)nq, dp, (int)t_base, margin,
                        d_idx, d_dist, d_counter, d_flagged, use_range ? d_rlist : (int *)nullptr, d_theta);
+    {   // all-zero queries share one closed-form answer (their number is only known on the device yet)
+        int *d_zidx = d_counter + 64;
+        float *d_zdist = reinterpret_cast<float *>(d_counter + 128);
+        hipLaunchKernelGGL(zero_answer_kernel, dim3(1), dim3(1024), 0, st, (const unsigned *)d_bits, (int)nt,
+                           (int)t_base, k, d_zidx, d_zdist);
+        hipLaunchKernelGGL(scatter_zero_answer_kernel, dim3((unsigned)(((int64_t)nq * k + 255) / 256)),
+                           dim3(256), 0, st, (const int *)d_zidx, (const float *)d_zdist,
+                           (const int *)d_flagged, (int)nq, (const int *)d_counter, k, d_idx, d_dist);
+    }
     HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
 
@@ -2357,16 +2439,6 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
         HIP_TRY(hipMemcpyAsync(counts, d_counter, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         count = counts[0];
-    }
-    if (zcount > 0) {  // all-zero queries share one closed-form answer
-        int *d_zidx = d_counter + 64;
-        float *d_zdist = reinterpret_cast<float *>(d_counter + 128);
-        hipLaunchKernelGGL(zero_answer_kernel, dim3(1), dim3(1024), 0, st, d_tzero, (int)nt, (int)t_base, k,
-                           d_zidx, d_zdist);
-        hipLaunchKernelGGL(scatter_zero_answer_kernel, dim3((unsigned)(((int64_t)zcount * k + 255) / 256)),
-                           dim3(256), 0, st, (const int *)d_zidx, (const float *)d_zdist,
-                           (const int *)(d_flagged + (nq - zcount)), zcount, k, d_idx, d_dist);
-        HIP_TRY(hipGetLastError());
     }
     if (count <= 0) return FDR_OK;
     if ((int64_t)count * 2 > nq - zcount)  // the prefilter did not help on this input: exact pass for everyone
