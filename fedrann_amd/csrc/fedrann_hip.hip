@@ -1046,15 +1046,18 @@ __device__ __forceinline__ u64 wave_sort64(u64 key, const int lane) {
 // P1's merge: the KP smallest keys of a query's nseg segment lists, sorted.  One wave per query.
 // A segment list arrives as two ascending halves ([0, ceil(KP/2)) and the rest; KEY_INF = empty slot),
 // so a full list's maximum is the larger of the two last entries, and the smallest such maximum over
-// the segments bounds the query's KP-th key: usually little more than KP keys survive that bound, they
-// are compacted into LDS and sorted with one 64-lane bitonic network.  More than 64 survivors (wide
-// plateaus), or no full list: KP rounds of a wave-wide minimum over all keys.
+// the segments bounds the query's KP-th key.  About KP * (rows / rows of the longest segment) keys
+// survive that bound (74 of 140 for the usual five segments); they are compacted into LDS, the first 64
+// are sorted with a 64-lane bitonic network, whose KP-th key is a tighter bound for the rest, and a
+// second sort of the KP best + the few remaining survivors finishes.  More than 128 survivors (wide
+// plateaus), more than 64 in the second sort, or no full list: KP rounds of a wave-wide minimum.
 __global__ __launch_bounds__(256) void knn_merge_keys_kernel(const u64 *__restrict__ partial, int nseg,
                                                              int nq, int nq_pad, int KP,
                                                              u64 *__restrict__ cand) {
     __shared__ u64 stage[4][MERGE_CAP];
-    __shared__ u64 surv[4][64];
+    static_assert(MERGE_CAP >= 128, "a wave's stage row doubles as its survivor buffer (128 keys)");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 *sv = stage[wave];
     const int q = blockIdx.x * 4 + wave;
     if (q >= nq) return;
     const int M = nseg * KP;
@@ -1088,7 +1091,7 @@ __global__ __launch_bounds__(256) void knn_merge_keys_kernel(const u64 *__restri
                     const bool keep = kv <= bound;  // (bound < KEY_INF)
                     const u64 mask = __ballot(keep);
                     const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (keep && pos < 64) surv[wave][pos] = kv;
+                    if (keep && pos < 128) sv[pos] = kv;
                     total += __popcll(mask);
                 }
                 sg0 += 8;
@@ -1096,10 +1099,28 @@ __global__ __launch_bounds__(256) void knn_merge_keys_kernel(const u64 *__restri
                 load_batch(sg0);
             }
         }
-        if (bound != KEY_INF && total <= 64) {  // (total >= KP: the bounding list alone has KP such keys)
-            const u64 kv = wave_sort64(lane < total ? surv[wave][lane] : KEY_INF, lane);
-            if (lane < KP) cand[(size_t)q * KP + lane] = kv;
-            return;
+        if (bound != KEY_INF && total <= 128) {  // (total >= KP: the bounding list alone has KP such keys)
+            u64 kv = wave_sort64(lane < total ? sv[lane] : KEY_INF, lane);
+            bool done = total <= 64;
+            if (!done) {
+                const u64 b2 = __shfl(kv, KP - 1);  // KP-th of the first 64: nothing above it is needed
+                const u64 extra = 64 + lane < total ? sv[64 + lane] : KEY_INF;
+                const bool keep = extra <= b2;
+                const u64 mask = __ballot(keep);
+                const int nx = __popcll(mask);
+                if (KP + nx <= 64) {
+                    const int pos = KP + __popcll(mask & ((1ull << lane) - 1ull));
+                    // second sort: lanes [0, KP) keep their key, the extras are appended through LDS
+                    if (keep) sv[pos] = extra;
+                    const u64 merged = lane < KP ? kv : (lane < KP + nx ? sv[lane] : KEY_INF);
+                    kv = wave_sort64(merged, lane);
+                    done = true;
+                }
+            }
+            if (done) {
+                if (lane < KP) cand[(size_t)q * KP + lane] = kv;
+                return;
+            }
         }
     }
     const bool staged = M <= MERGE_CAP;
@@ -1163,8 +1184,10 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
         }
         return;
     }
+    // A candidate with d~ > d~(K) + M has an exact distance above d~(K) + eps + 4e-7, i.e. above the exact
+    // distances of the K candidates with the smallest d~: it cannot be in the top K, so its row is not read.
     u64 exact = ~0ull;
-    if (lane < KP && key < KEY_INF) {
+    if (lane < KP && key < KEY_INF && dt <= dK + margin) {
         const int tidx = (int)(unsigned)(key & 0xffffffffull);
         const f32x4 *qp = reinterpret_cast<const f32x4 *>(Qhat + (size_t)q * DP);
         const f32x4 *tp = reinterpret_cast<const f32x4 *>(That + (size_t)(tidx - t_base) * DP);
