@@ -1541,6 +1541,32 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(const float *__restrict_
     }
 }
 
+// Cheap estimate of the number of duplicate rows, to decide whether the class machinery is worth
+// running at all: every row hash goes into an open-addressing table (linear probing, at most 16
+// steps); a row that finds its own hash already present counts as a duplicate.  counter[0] += count.
+__global__ __launch_bounds__(256) void dedup_probe_kernel(const u64 *__restrict__ hash, int n,
+                                                          u64 *__restrict__ table, unsigned tmask,
+                                                          int *__restrict__ counter) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool dup = false;
+    if (i < n) {
+        const u64 hv = hash[i] | 1ull;  // (0 = empty slot)
+        unsigned slot = (unsigned)(hv >> 20) & tmask;
+        for (int step = 0; step < 16; ++step) {
+            const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(table + slot), 0ull,
+                                      (unsigned long long)hv);
+            if (old == 0ull) break;
+            if (old == hv) {
+                dup = true;
+                break;
+            }
+            slot = (slot + 1) & tmask;
+        }
+    }
+    const int c = __popcll(__ballot(dup));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(counter, c);
+}
+
 // flag[p] = 1 if sorted position p starts a new class (hash differs or the rows differ)
 __global__ __launch_bounds__(256) void mark_class_starts_kernel(const float *__restrict__ X, int n, int DP,
                                                                 const u64 *__restrict__ hash_s,
@@ -2586,6 +2612,32 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     if (trc) return trc;
     hipLaunchKernelGGL(hash_rows_kernel, dim3(g16), dim3(256), 0, st, d_That, n, dp, hash, idx);
     HIP_TRY(hipGetLastError());
+    const char *knob = getenv("FDR_KNN_DEDUP");
+    const bool always = knob && atoi(knob) == 2;  // development knob: expand even without duplicates
+    if (!always) {
+        // a hash-table probe (~15 us) tells whether enough rows repeat to pay for the sort and the tables;
+        // the table borrows the (still unused) unique-row buffer
+        unsigned tsize = 1024;
+        while (tsize < 2u * (unsigned)n && tsize < (1u << 30)) tsize <<= 1;
+        if ((size_t)tsize * 8 + 256 <= (size_t)nt * dp * 4) {
+            u64 *table = reinterpret_cast<u64 *>(U);
+            int *d_cnt = reinterpret_cast<int *>(table + tsize);
+            HIP_TRY(hipMemsetAsync(table, 0, (size_t)tsize * 8 + 4, st));
+            hipLaunchKernelGGL(dedup_probe_kernel, dim3(g1), dim3(256), 0, st, (const u64 *)hash, n, table,
+                               tsize - 1, d_cnt);
+            HIP_TRY(hipGetLastError());
+            int dups = 0;
+            HIP_TRY(hipMemcpyAsync(&dups, d_cnt, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if ((double)dups < 0.05 * (double)n) {  // (unique share)^2 > 0.9: not worth it
+                if ((trc = timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st))) return trc;
+                ctx->last_unique_targets = (int)nt;
+                ctx->last_unique_queries = (int)nq;
+                return launch_knn_mode(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx,
+                                       d_dist, d_ws, L.inner_bytes, st);
+            }
+        }
+    }
     size_t tb = L.tmp_bytes;
     HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, hash, hash_s, idx, idx_s, (size_t)n, 0, 64, st));
     hipLaunchKernelGGL(mark_class_starts_kernel, dim3(g1), dim3(256), 0, st, d_That, n, dp,
@@ -2610,8 +2662,6 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     HIP_TRY(hipStreamSynchronize(st));
     ctx->last_unique_targets = nu;
     ctx->last_unique_queries = nuq;
-    const char *knob = getenv("FDR_KNN_DEDUP");
-    const bool always = knob && atoi(knob) == 2;  // development knob: expand even without duplicates
     const bool worth = nu >= k && (always || (double)nu * nuq <= 0.9 * (double)nt * (double)nq);
     size_t inner_need = worth ? knn_mode_workspace_bytes(ctx, nuq, nu, d, k) : 0;
     if (!worth || inner_need > L.inner_bytes) {  // few duplicates (or, never seen, no room): plain search
