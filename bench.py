@@ -158,8 +158,8 @@ def main():
         dt = time.perf_counter() - t0
         kms, kcnt = {}, {}
         for i, name in enumerate(_lib.KERNELS):
-            cnt, ms = ctx.timing_read(i)
-            kms[name] = ms / max(cnt, 1)
+            cnt, ms = ctx.timing_read(i)  # timed spans of this kind since the last read, their total
+            kms[name] = ms / max(steps, 1)  # per step (a kind may have several spans per step)
             kcnt[name] = cnt / max(steps, 1)
         ctx.timing(False)
         if world > 1:
