@@ -11,8 +11,9 @@ ONT reads, 128-dim projection, k-NN = 20.  Inputs (the read x k-mer CSR and the 
 tables) are resident in HBM before the timed region; results stay in HBM.  The total work is the
 same for every N (strong scaling): value = R * k * steps / time.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (knn_tile, fp32 MFMA);
-`cpu_baseline` times this repo's CPU oracle (a port of the path, not the reference's pynndescent,
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the timed mode (the fp16 MFMA
+prefilter pass by default, the fp32 MFMA tile kernel in exact mode), priced on the unique rows it
+actually searched; `cpu_baseline` times this repo's CPU oracle (a port of the path, not the reference's pynndescent,
 which is not installed) on a bounded sample of the same workload.
 """
 import argparse
@@ -112,11 +113,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # FEDRANN_BENCH_REHEARSE=1: every rank on GPU 0 over gloo -- a one-GPU rehearsal of the N > 1 code path
+    # (sharding, exchange, per-rank k-NN, reductions); never a measurement
+    rehearse = os.environ.get("FEDRANN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from fedrann_amd import _lib
     from fedrann_amd.distributed import HipEngine, ShardedPipeline, local_csr

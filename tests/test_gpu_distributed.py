@@ -1,0 +1,50 @@
+"""The N > 1 path with the real device stages: 2 and 3 ranks (separate processes) share GPU 0 and
+exchange their normalised row blocks over gloo; the concatenated result must equal the oracle's
+unsharded answer bit for bit.  (RCCL itself needs one GPU per rank: the driver's scaling run covers it.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from fedrann_amd.precompute import build_precompute_matrix
+from fedrann_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,R,d,k", [(2, 30_000, 128, 20), (3, 9_001, 200, 50)])
+def test_sharded_pipeline_on_gpu_matches_oracle(tmp_path, oracle, world, R, d, k):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker.py"), str(tmp_path),
+                                       str(R), str(d), str(k)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    s = synth(R, seed=23, m=60)
+    P = build_precompute_matrix(s["counts"], d)
+    E = oracle.embed(s["indptr"], s["indices"], (P.indptr, P.indices, P.data), s["n_features"], d)
+    wi, wd = oracle.knn(E, k)
+    rows = 0
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        lo, hi = int(z["lo"]), int(z["hi"])
+        assert lo == rows
+        rows = hi
+        assert np.array_equal(z["E"].view(np.uint32), E[lo:hi].view(np.uint32))
+        assert np.array_equal(z["idx"], wi[lo:hi])
+        assert np.array_equal(z["dist"].view(np.uint32), wd[lo:hi].view(np.uint32))
+    assert rows == E.shape[0]
