@@ -15,7 +15,8 @@ SYMBOLS = (
     "fdr_create", "fdr_destroy", "fdr_last_error", "fdr_device_info", "fdr_padded_dim",
     "fdr_projection_load", "fdr_embed", "fdr_knn", "fdr_embed_knn", "fdr_embed_dev",
     "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_timing", "fdr_timing_read",
-    "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_last_unique",
+    "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_last_unique", "fdr_kmer_output_scan",
+    "fdr_kmer_output_load",
 )
 FDR_MAX_K = 64
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
@@ -80,6 +81,9 @@ def load_library():
     L.fdr_last_uncertified.argtypes = [vp]
     L.fdr_set_knn_mode.argtypes = [vp, ctypes.c_int]
     L.fdr_last_unique.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    p64 = ctypes.POINTER(ctypes.c_int64)
+    L.fdr_kmer_output_scan.argtypes = [ctypes.c_char_p, p64, p64, p64]
+    L.fdr_kmer_output_load.argtypes = [ctypes.c_char_p, i64, i32, vp, vp, vp, vp]
     L.fdr_timing.argtypes = [vp, ctypes.c_int]
     L.fdr_timing_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(ctypes.c_float)]
@@ -100,6 +104,26 @@ def _as(a, dtype, name):
     if b.dtype != np.dtype(dtype):
         raise TypeError("%s must be %s" % (name, np.dtype(dtype)))
     return b
+
+
+def kmer_output_load(path, n_features, n_threads=0):
+    """output.bin -> (indptr int64 [2R+1], indices int32 ascending per row, name_off int64 [R+1],
+    names uint8 buffer) through fdr_kmer_output_scan / fdr_kmer_output_load (host only, no GPU)."""
+    L = load_library()
+    bpath = os.fsencode(path)
+    R, nnz, nb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    rc = L.fdr_kmer_output_scan(bpath, ctypes.byref(R), ctypes.byref(nnz), ctypes.byref(nb))
+    if rc != 0:
+        raise FedrannHipError("fdr_kmer_output_scan failed (%d): %s" % (rc, L.fdr_last_error().decode()))
+    indptr = np.empty(2 * R.value + 1, dtype=np.int64)
+    indices = np.empty(2 * nnz.value, dtype=np.int32)
+    name_off = np.empty(R.value + 1, dtype=np.int64)
+    names = np.empty(nb.value, dtype=np.uint8)
+    rc = L.fdr_kmer_output_load(bpath, int(n_features), int(n_threads), indptr.ctypes.data,
+                                indices.ctypes.data, name_off.ctypes.data, names.ctypes.data)
+    if rc != 0:
+        raise FedrannHipError("fdr_kmer_output_load failed (%d): %s" % (rc, L.fdr_last_error().decode()))
+    return indptr, indices, name_off, names
 
 
 class Context:

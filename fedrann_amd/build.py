@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "fedrann_hip.hip")
 OUT = os.path.join(HERE, "libfedrann_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-result", "-pthread"]
 
 
 def hipcc_path():
@@ -20,7 +20,8 @@ def hipcc_path():
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    deps = [SRC, os.path.join(HERE, "..", "include", "fedrann_hip.h")]
+    deps = [SRC, os.path.join(HERE, "csrc", "kmer_output_loader.inc"),
+            os.path.join(HERE, "..", "include", "fedrann_hip.h")]
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 

@@ -2817,3 +2817,5 @@ FDR_EXPORT int fdr_embed_knn(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indp
     if (E_out) HIP_TRY(hipMemcpyAsync(E_out, ctx->E.p, ebytes, hipMemcpyDeviceToHost, ctx->stream));
     return knn_from_device_E(ctx, (const float *)ctx->E.p, n_rows, ctx->d, k, idx_out, dist_out);
 }
+
+#include "kmer_output_loader.inc"

@@ -126,25 +126,42 @@ def canonical_csr(indptr, indices, n_features, what="feature matrix"):
     return indptr, np.ascontiguousarray(indices, dtype=np.int32)
 
 
-def build_feature_csr(ks_file, n_features):
+def _decode_names(name_off, name_buf):
+    """Record ids as str: UTF-8, or -- for ids that are not valid UTF-8 -- ASCII with every byte >= 128
+    replaced by '_' (feature_extraction.py:125-128)."""
+    raw = name_buf.tobytes()
+    off = name_off.tolist()
+    try:
+        if raw.isascii():
+            txt = raw.decode("ascii")  # one decode; byte offsets are character offsets
+            return [txt[off[r]:off[r + 1]] for r in range(len(off) - 1)]
+    except AttributeError:
+        pass
+    names = []
+    for r in range(len(off) - 1):
+        b = raw[off[r]:off[r + 1]]
+        try:
+            names.append(b.decode("utf-8"))
+        except UnicodeDecodeError:
+            names.append("".join(chr(c) if c < 128 else "_" for c in b))
+    return names
+
+
+def build_feature_csr(ks_file, n_features, n_threads=0):
     """output.bin -> binary CSR of the 2R doubled rows (row 2i = record i, row 2i+1 = its strand
-    mirror: i + L if i < L else i - L; feature_extraction.py:136-140).
+    mirror: i + L if i < L else i - L; feature_extraction.py:136-140), parsed, mirrored and sorted by
+    the native loader (fdr_kmer_output_load; no Python fallback).
     Returns (indptr, indices int32 sorted, read_names, strands)."""
-    names, rp, idx = read_kmer_searcher_output(ks_file)
-    L = int(n_features) // 2
-    R = len(names)
-    cnt = np.diff(rp)
-    indptr = np.zeros(2 * R + 1, dtype=np.int64)
-    np.cumsum(np.repeat(cnt, 2), out=indptr[1:])
-    mirrored = np.where(idx < L, idx + L, idx - L)
-    out = np.empty(2 * idx.size, dtype=np.int64)
-    # interleave per record: [fwd block][rev block]
-    dst_fwd = np.repeat(indptr[0:-1:2] - rp[:-1], cnt) + np.arange(idx.size, dtype=np.int64)
-    out[dst_fwd] = idx
-    out[dst_fwd + np.repeat(cnt, cnt)] = mirrored
-    indptr, indices = canonical_csr(indptr, out, n_features, what=ks_file)
+    try:
+        indptr, indices, name_off, name_buf = _lib.kmer_output_load(ks_file, int(n_features), n_threads)
+    except _lib.FedrannHipError as e:
+        msg = str(e)
+        if "output.bin:" in msg:  # format errors keep the reference's exception type
+            raise ValueError(msg.split("output.bin:", 1)[1].strip()) from None
+        raise
+    names = _decode_names(name_off, name_buf)
     read_names = [n for n in names for _ in (0, 1)]
-    strands = [0, 1] * R
+    strands = [0, 1] * len(names)
     return indptr, indices, read_names, strands
 
 

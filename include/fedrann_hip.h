@@ -37,6 +37,7 @@ extern "C" {
 #define FDR_E_HIP (-2)     /* a HIP runtime call or kernel launch failed */
 #define FDR_E_NOMEM (-4)   /* device or host allocation failed */
 #define FDR_E_STATE (-5)   /* call order (e.g. embed before a projection was loaded) */
+#define FDR_E_IO (-6)      /* a file could not be opened / mapped */
 
 #define FDR_MAX_K 64       /* neighbours per row (self included) supported by the top-k kernel */
 #define FDR_MAX_DIM 512    /* embedding dimension supported by the k-NN kernel (reference default: 500) */
@@ -134,6 +135,22 @@ int fdr_last_unique(fdr_ctx *ctx, int *unique_targets, int *unique_queries);
 /* Prefilter mode only: number of query rows of the most recent k-NN call whose candidate set could
  * not be certified and that were therefore searched by the exact kernel. */
 int fdr_last_uncertified(fdr_ctx *ctx);
+
+/* ---- kmer_searcher output.bin -> doubled binary CSR (host only: no context, no GPU) ---------------
+ * Replaces fedrann/feature_extraction.py:108-140 (parse_kmer_searcher_output: header '<4sB3sQ' =
+ * "KMER", version 1, record count; per record '<H' id length, id bytes, '<I' index count, that many
+ * '<Q' feature indices; a record yields its index set and the strand mirror i + L if i < L else i - L,
+ * L = n_features / 2) together with the COO -> CSR conversion of :191-204 (ascending columns per row).
+ * Row 2r = record r, row 2r + 1 = its mirror.  Two calls, caller-allocated outputs:
+ *   fdr_kmer_output_scan: record count R, sum of index counts nnz, sum of id lengths;
+ *   fdr_kmer_output_load: indptr int64 [2R + 1], indices int32 [2 nnz], name_off int64 [R + 1],
+ *                         names [name_bytes] (raw id bytes, record r at name_off[r] .. name_off[r+1]).
+ * n_threads <= 0: all hardware threads.  Errors as in the reference (bad magic / version, short
+ * header -> FDR_E_ARG), plus truncated records, indices outside [0, n_features) and repeated indices
+ * inside a record (the reference would sum them; kmer_searcher emits sets). */
+int fdr_kmer_output_scan(const char *path, int64_t *n_records, int64_t *nnz, int64_t *name_bytes);
+int fdr_kmer_output_load(const char *path, int64_t n_features, int32_t n_threads, int64_t *indptr,
+                         int32_t *indices, int64_t *name_off, char *names);
 
 #ifdef __cplusplus
 }

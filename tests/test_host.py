@@ -114,6 +114,55 @@ def test_output_bin_errors(tmp_path):
     assert names == [] and indptr.tolist() == [0] and idx.size == 0
 
 
+def test_native_output_bin_loader_errors(tmp_path):
+    """fdr_kmer_output_load: the reference's format errors (feature_extraction.py:111-119) as ValueError,
+    plus truncation, out-of-range and repeated indices; a missing file is an I/O error of the library."""
+    from fedrann_amd import _lib
+    p = tmp_path / "x.bin"
+    hdr = lambda magic, ver, n: struct.pack("<4sB3sQ", magic, ver, b"\0\0\0", n)
+    rec = lambda name, idx: (struct.pack("<H", len(name)) + name + struct.pack("<I", len(idx))
+                             + struct.pack("<%dQ" % len(idx), *idx))
+    cases = [b"KME", hdr(b"XXXX", 1, 0), hdr(b"KMER", 2, 0),
+             hdr(b"KMER", 1, 1) + struct.pack("<H", 2) + b"ab" + struct.pack("<I", 3) + struct.pack("<2Q", 1, 2),
+             hdr(b"KMER", 1, 2) + rec(b"a", [1, 2]),          # second record missing
+             hdr(b"KMER", 1, 1) + rec(b"a", [1, 10]),         # index == n_features
+             hdr(b"KMER", 1, 1) + rec(b"a", [3, 4, 3])]       # repeated index
+    for blob in cases:
+        p.write_bytes(blob)
+        with pytest.raises(ValueError):
+            fx.build_feature_csr(str(p), 10)
+    with pytest.raises(_lib.FedrannHipError):
+        fx.build_feature_csr(str(tmp_path / "missing.bin"), 10)
+    p.write_bytes(hdr(b"KMER", 1, 1) + rec(b"a", [1]))
+    with pytest.raises(_lib.FedrannHipError):
+        fx.build_feature_csr(str(p), 9)  # F must be even (F = 2L)
+    p.write_bytes(hdr(b"KMER", 1, 0))
+    indptr, indices, names, strands = fx.build_feature_csr(str(p), 10)
+    assert indptr.tolist() == [0] and indices.size == 0 and names == [] and strands == []
+
+
+@pytest.mark.parametrize("threads", [1, 0, 5])
+def test_native_output_bin_loader_large_random(tmp_path, oracle, threads):
+    """20 k records (enough for the thread pool to engage), ragged incl. empty records, long ids."""
+    rng = np.random.default_rng(5)
+    L = 40_000
+    R = 20_000
+    names = ["read_%d_%s" % (i, "x" * int(rng.integers(0, 30))) for i in range(R)]
+    names[17] = b"\xc3\x28 not utf8"
+    names[18] = "caf\u00e9"
+    lens = rng.integers(0, 60, size=R)
+    lens[::97] = 0
+    rows = [rng.choice(2 * L, size=int(n), replace=False) for n in lens]
+    p = tmp_path / "output.bin"
+    _write_output_bin(p, names, rows)
+    o_names, o_strands, o_rows = oracle.parse_output_bin(str(p), L)
+    indptr, indices, n3, s3 = fx.build_feature_csr(str(p), 2 * L, n_threads=threads)
+    assert n3 == o_names and s3 == o_strands
+    assert indptr.dtype == np.int64 and indices.dtype == np.int32
+    want_ptr, want_idx = oracle.rows_to_csr([sorted(r) for r in o_rows])
+    assert np.array_equal(indptr, want_ptr) and np.array_equal(indices, want_idx)
+
+
 def test_canonical_csr_checks():
     ip, ix = fx.canonical_csr([0, 3, 3, 5], [9, 2, 4, 7, 1], 10)
     assert ix.tolist() == [2, 4, 9, 1, 7] and ix.dtype == np.int32 and ip.dtype == np.int64
