@@ -1,6 +1,9 @@
 #!/bin/bash
-# development sweep: prefilter candidate slack (FDR_KNN_EXTRA) -> kernel times and uncertified count
-for ex in "$@"; do
-  out=$(FDR_KNN_EXTRA=$ex python bench.py --steps 3 --warmup 1 --cpu-baseline-seconds 0 --no-compare --mode prefilter $BENCH_ARGS 2>/dev/null | python -c "import json,sys; r=json.load(sys.stdin); k=r['kernels_ms']; print('%.1f Mpairs/s  %.2f ms/step  prefilter %.2f  rerank %.2f  exact-fallback %.2f ms/launch  uncertified %s' % (r['value']/1e6, r['ms_per_step'], k['knn_prefilter'], k['knn_rerank'], k['knn_tile'], r['uncertified_queries_last_step']))")
-  echo "extra=$ex : $out"
-done
+# candidates kept beyond k in the prefilter pass (FDR_KNN_EXTRA): step time and uncertified queries
+for cfg in "100000 128 20" "1000000 128 20" "100000 128 50"; do set -- $cfg; for ex in 4 6 8 12; do
+  FDR_KNN_EXTRA=$ex python bench.py --reads $1 --dim $2 --knn $3 --steps 3 --warmup 1 --cpu-baseline-seconds 0 --no-compare > gpurun_out/ex.json 2> gpurun_out/ex.err
+  python - <<PY
+import json
+j=json.load(open("gpurun_out/ex.json")); print("reads", $1, "k", $3, "extra", $ex, round(j["value"]/1e6,1), "M/s", round(j["ms_per_step"],3), "ms  P1", round(j["kernels_ms"]["knn_prefilter"],3), "rerank", round(j["kernels_ms"]["knn_rerank"],3), "uncert", j["uncertified_queries_last_step"])
+PY
+done; done

@@ -16,7 +16,7 @@ import argparse
 import logging
 import os
 from os.path import abspath, join
-from shutil import rmtree
+from shutil import copyfileobj, rmtree
 from typing import List
 
 import numpy as np
@@ -201,6 +201,29 @@ def run_fedrann_pipeline(*, output_dir, embedding_dimension, nndescent_n_trees,
     logger.info("Pipeline completed.")
 
 
+def _gpu_kmer_search(reads_path, fwd_library, k, temp_dir):
+    """reads + forward library -> temp/kmer_searcher/output.bin (and kmer_frequency.bin).  The reverse
+    library is the reverse complement of every forward k-mer, in the same order (`seqkit seq -r -p`,
+    count_kmers.py:127); both are passed in the reference's order: forward, then reverse."""
+    from .kmer_search import kmer_searcher
+    comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+    with open(fwd_library, "rb") as f:
+        lines = f.read().split(b"\n")
+    rev_path = join(temp_dir, "rev_kmer_library.fasta")
+    with open(rev_path, "wb") as f:
+        f.write(b"\n".join(l if l.startswith(b">") else l.translate(comp)[::-1] for l in lines))
+    if reads_path.endswith(".gz"):
+        import gzip
+        plain = join(temp_dir, os.path.basename(reads_path[:-3]))
+        with gzip.open(reads_path, "rb") as src, open(plain, "wb") as dst:
+            copyfileobj(src, dst, 1 << 24)
+        reads_path = plain
+    out_dir = join(temp_dir, "kmer_searcher")
+    ids, indptr, indices, n_lib = kmer_searcher([fwd_library, rev_path], reads_path, out_dir, k)
+    logger.debug("k-mer search: %d reads, %d library k-mers, %d hits", len(ids), n_lib, indices.size)
+    return join(out_dir, "output.bin")
+
+
 def main(argv=None):
     args = parse_command_line_arguments(argv)
     global_variables.threads = args.threads
@@ -218,13 +241,18 @@ def main(argv=None):
     logger.debug("Parameters: %s", args)
     have_ks = bool(args.kmer_searcher_output)
     have_fm = bool(args.feature_matrix)
+    if args.input and args.kmer_library and not have_ks and not have_fm:
+        # stage 1b on the GPU: reads x sampled k-mer library -> output.bin (count_kmers.py:119-139 with the
+        # reverse library made here instead of by seqkit, the search by fdr_kmer_search instead of kmer_searcher)
+        logger.info("--- 1b. k-mer search on the GPU ---")
+        args.kmer_searcher_output = _gpu_kmer_search(args.input, args.kmer_library, args.kmer_size, temp_dir)
+        have_ks = True
     if have_ks == have_fm:
         raise SystemExit(
-            "give exactly one of --kmer-searcher-output (+ --kmer-library) or --feature-matrix "
-            "(+ --kmer-counts).  K-mer counting, sampling and kmer_searcher (stage 1 of the "
-            "reference, -i/--input) are not part of this build: run the reference with "
-            "--keep-intermediates and pass its temp/kmer_searcher/output.bin and "
-            "temp/fwd_kmer_library.fasta here.")
+            "give exactly one of --kmer-searcher-output (+ --kmer-library), -i reads (+ --kmer-library) or "
+            "--feature-matrix (+ --kmer-counts).  K-mer counting and sampling (jellyfish + awk, the first "
+            "half of stage 1 of the reference) are not part of this build: run the reference with "
+            "--keep-intermediates and pass its temp/fwd_kmer_library.fasta here.")
     if have_ks and not args.kmer_library:
         raise SystemExit("--kmer-searcher-output needs --kmer-library")
     if have_fm and not args.kmer_counts:

@@ -16,11 +16,11 @@ SYMBOLS = (
     "fdr_projection_load", "fdr_embed", "fdr_knn", "fdr_embed_knn", "fdr_embed_dev",
     "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_timing", "fdr_timing_read",
     "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_last_unique", "fdr_kmer_output_scan",
-    "fdr_kmer_output_load",
+    "fdr_kmer_output_load", "fdr_kmer_search", "fdr_kmer_search_indices",
 )
 FDR_MAX_K = 64
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
-           "knn_dedup")
+           "knn_dedup", "kmer_search", "kmer_compact")
 FDR_MAX_DIM = 512
 
 
@@ -84,6 +84,8 @@ def load_library():
     p64 = ctypes.POINTER(ctypes.c_int64)
     L.fdr_kmer_output_scan.argtypes = [ctypes.c_char_p, p64, p64, p64]
     L.fdr_kmer_output_load.argtypes = [ctypes.c_char_p, i64, i32, vp, vp, vp, vp]
+    L.fdr_kmer_search.argtypes = [vp, vp, vp, i64, vp, i64, i32, vp, p64]
+    L.fdr_kmer_search_indices.argtypes = [vp, vp]
     L.fdr_timing.argtypes = [vp, ctypes.c_int]
     L.fdr_timing_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(ctypes.c_float)]
@@ -181,6 +183,23 @@ class Context:
         """mode: "auto" (default), "exact" or "prefilter" -- same results, see include/fedrann_hip.h."""
         code = {"auto": 0, "exact": 1, "prefilter": 2}[mode]
         self._check(self._L.fdr_set_knn_mode(self._h, code), "fdr_set_knn_mode")
+
+    def kmer_search(self, seqs, seq_off, lib_codes, k):
+        """Per-read ascending unique library indices: (indptr int64 [R+1], indices int32 [nnz])."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        lib_codes = np.ascontiguousarray(lib_codes, dtype=np.uint64)
+        R = seq_off.size - 1
+        if R < 0 or (R >= 0 and seq_off.size and int(seq_off[-1]) != seqs.size):
+            raise ValueError("seq_off does not describe seqs")
+        indptr = np.empty(R + 1, dtype=np.int64)
+        nnz = ctypes.c_int64()
+        self._check(self._L.fdr_kmer_search(self._h, seqs.ctypes.data, seq_off.ctypes.data, R,
+                                            lib_codes.ctypes.data, lib_codes.size, int(k), indptr.ctypes.data,
+                                            ctypes.byref(nnz)), "fdr_kmer_search")
+        indices = np.empty(nnz.value, dtype=np.int32)
+        self._check(self._L.fdr_kmer_search_indices(self._h, indices.ctypes.data), "fdr_kmer_search_indices")
+        return indptr, indices
 
     def last_unique(self):
         """(unique target rows, unique query rows) searched by the last k-NN call."""

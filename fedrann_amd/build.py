@@ -20,7 +20,7 @@ def hipcc_path():
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    deps = [SRC, os.path.join(HERE, "csrc", "kmer_output_loader.inc"),
+    deps = [SRC, os.path.join(HERE, "csrc", "kmer_output_loader.inc"), os.path.join(HERE, "csrc", "kmer_search.inc"),
             os.path.join(HERE, "..", "include", "fedrann_hip.h")]
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 

@@ -1762,6 +1762,10 @@ struct fdr_ctx {
     DevBuf ftab, crow, ent;
     // scratch for the host-pointer API
     DevBuf a_indptr, a_indices, E, Ehat, zero, idx, dist, ws;
+    // k-mer search (kmer_search.inc)
+    DevBuf ks_seq, ks_off, ks_codes, ks_keys, ks_vals, ks_bloom, ks_counter, ks_pairs, ks_pairs2, ks_flag, ks_pos,
+        ks_idx, ks_rows, ks_indptr, ks_tmp;
+    long long ks_nnz = 0;
     // timing: when enabled, every launch of kernel kind i gets its own hipEvent pair on the launch
     // stream; fdr_timing_read() sums the elapsed times of all launches since the last read
     int knn_mode = FDR_MODE_AUTO;
@@ -1769,7 +1773,7 @@ struct fdr_ctx {
     int last_unique_targets = 0, last_unique_queries = 0;  // duplicate-row classes of the last call
     bool timing = false;
     std::vector<hipEvent_t> ev_pool[FDR_NUM_KERNELS];  // start, stop, start, stop, ...
-    size_t ev_used[FDR_NUM_KERNELS] = {0, 0, 0, 0, 0, 0, 0};
+    size_t ev_used[FDR_NUM_KERNELS] = {};
 };
 
 static int timing_begin(fdr_ctx *ctx, int kind, hipStream_t st) {
@@ -1833,7 +1837,10 @@ FDR_EXPORT int fdr_destroy(fdr_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->ftab, &ctx->crow, &ctx->ent, &ctx->a_indptr, &ctx->a_indices, &ctx->E,
-                      &ctx->Ehat, &ctx->zero, &ctx->idx, &ctx->dist, &ctx->ws};
+                      &ctx->Ehat, &ctx->zero, &ctx->idx, &ctx->dist, &ctx->ws,
+                      &ctx->ks_seq, &ctx->ks_off, &ctx->ks_codes, &ctx->ks_keys, &ctx->ks_vals, &ctx->ks_bloom,
+                      &ctx->ks_counter, &ctx->ks_pairs, &ctx->ks_pairs2, &ctx->ks_flag, &ctx->ks_pos,
+                      &ctx->ks_idx, &ctx->ks_rows, &ctx->ks_indptr, &ctx->ks_tmp};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < FDR_NUM_KERNELS; ++i)
         for (hipEvent_t e : ctx->ev_pool[i]) (void)hipEventDestroy(e);
@@ -2818,4 +2825,5 @@ FDR_EXPORT int fdr_embed_knn(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indp
     return knn_from_device_E(ctx, (const float *)ctx->E.p, n_rows, ctx->d, k, idx_out, dist_out);
 }
 
+#include "kmer_search.inc"
 #include "kmer_output_loader.inc"

@@ -1,0 +1,174 @@
+"""reads x k-mer library -> per-read sets of library indices, on the GPU.
+
+Host-side mirror of the reference's native tool `kmer_searcher` (kmer_searcher/kmer_searcher.cpp) as
+fedrann/count_kmers.py:131-139 drives it:
+
+    cat fwd_kmer_library.fasta rev_kmer_library.fasta | grep -v '^>' | kmer_searcher /dev/stdin reads.fasta OUT k threads
+
+    load_kmer_library   kmer_searcher.cpp:262-279  (tokens of length k, first occurrence wins)
+    read_sequences      kmer_searcher.cpp:153-200  (FASTA / FASTQ reader)
+    kmer_searcher       kmer_searcher.cpp:232-375  (the search: fdr_kmer_search on the GPU)
+    write_output_bin    kmer_searcher.cpp:98-130   (output.bin) and :203-230 (kmer_frequency.bin)
+
+The search itself has no CPU path: without libfedrann_hip.so and a GPU it raises.
+"""
+import os
+import struct
+
+import numpy as np
+
+from . import _lib
+
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _i, _c in enumerate("ACGT"):
+    _CODE[ord(_c)] = _i
+    _CODE[ord(_c.lower())] = _i
+_WS = np.zeros(256, dtype=bool)
+_WS[[9, 10, 11, 12, 13, 32]] = True  # what `istream >> std::string` skips
+
+
+def load_kmer_library(texts, k):
+    """Library text(s) -> uint64 codes of the unique valid k-mers, in index order.
+
+    `texts`: bytes or a list of bytes (concatenated as `cat` would).  Tokens are separated by white
+    space; a token whose length is not k (e.g. a '>count' header), a token with a character outside
+    ACGTacgt and a k-mer seen before are skipped (kmer_searcher.cpp:268-277).  Note that the reverse
+    library repeats every palindromic k-mer of the forward one; those lose their slot, as in the
+    reference."""
+    if not 1 <= int(k) <= 31:
+        raise ValueError("Invalid k value: %r" % (k,))  # kmer_searcher.cpp:246-249
+    if isinstance(texts, (bytes, bytearray, memoryview)):
+        texts = [texts]
+    data = np.frombuffer(b"".join(bytes(t) for t in texts), dtype=np.uint8)
+    if data.size == 0:
+        return np.zeros(0, dtype=np.uint64)
+    ws = _WS[data]
+    start = np.flatnonzero(~ws & np.concatenate(([True], ws[:-1])))
+    end = np.flatnonzero(~ws & np.concatenate((ws[1:], [True]))) + 1
+    start = start[end - start == k]
+    codes = np.zeros(start.size, dtype=np.uint64)
+    valid = np.ones(start.size, dtype=bool)
+    for j in range(k):  # k <= 31 passes over the token starts
+        c = _CODE[data[start + j]]
+        valid &= c != 255
+        codes = (codes << np.uint64(2)) | (c & 3).astype(np.uint64)
+    codes = codes[valid]
+    _, first = np.unique(codes, return_index=True)
+    first.sort()
+    return np.ascontiguousarray(codes[first])
+
+
+def read_sequences(path):
+    """FASTA / FASTQ -> (ids list of bytes, seqs uint8 [total], seq_off int64 [R+1]) exactly as
+    kmer_searcher.cpp:153-200 reads them: FASTQ iff the first line starts with '@'.  FASTA: id = header up
+    to the first space or tab; the sequence is every following line with only the '\\n' removed (a '\\r'
+    stays and is an invalid character); empty lines are skipped; a record whose id is empty, and anything
+    before the first header, is dropped.  FASTQ: id = the whole header line after '@', sequence = the
+    next line, then two lines are skipped."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    data = np.frombuffer(raw, dtype=np.uint8)
+    if data.size == 0:
+        return [], np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64)
+    nl = np.flatnonzero(data == 10)
+    starts = np.concatenate(([0], nl + 1))
+    ends = np.concatenate((nl, [data.size]))  # (exclusive, without the '\n')
+    if starts[-1] == data.size:               # the file ends with '\n': no further line
+        starts, ends = starts[:-1], ends[:-1]
+    lens = ends - starts
+    first = data[np.minimum(starts, data.size - 1)]
+    if lens[0] > 0 and first[0] == ord("@"):  # ---- FASTQ ----
+        ids, pieces, i, n = [], [], 0, starts.size
+        while i < n:
+            if lens[i] > 0 and first[i] == ord("@"):
+                ids.append(raw[starts[i] + 1:ends[i]])
+                pieces.append(raw[starts[i + 1]:ends[i + 1]] if i + 1 < n else b"")
+                i += 4
+            else:
+                i += 1
+        off = np.zeros(len(ids) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(p) for p in pieces])
+        return ids, np.frombuffer(b"".join(pieces), dtype=np.uint8), off
+    # ---- FASTA ----
+    nonempty = lens > 0
+    is_head = nonempty & (first == ord(">"))
+    rec_of_line = np.cumsum(is_head) - 1  # -1: before the first header
+    heads = np.flatnonzero(is_head)
+    ids = []
+    for h in heads.tolist():
+        line = raw[starts[h] + 1:ends[h]]
+        cut = len(line)
+        for sep in (b" ", b"\t"):
+            p = line.find(sep)
+            if 0 <= p < cut:
+                cut = p
+        ids.append(line[:cut])
+    has_id = np.array([len(x) > 0 for x in ids], dtype=bool)
+    keep_line = nonempty & ~is_head & (rec_of_line >= 0)
+    if has_id.size:
+        keep_line &= has_id[np.maximum(rec_of_line, 0)]
+    # bases = the bytes of the kept lines
+    span = np.diff(np.concatenate((starts, [data.size])))  # line length incl. its '\n'
+    mask = np.repeat(keep_line, span)
+    mask[nl] = False
+    seqs = np.ascontiguousarray(data[mask])
+    seq_len = np.bincount(rec_of_line[keep_line], weights=lens[keep_line], minlength=len(ids)).astype(np.int64)
+    seq_len = seq_len[has_id] if has_id.size else seq_len
+    off = np.zeros(seq_len.size + 1, dtype=np.int64)
+    np.cumsum(seq_len, out=off[1:])
+    return [x for x, ok in zip(ids, has_id) if ok], seqs, off
+
+
+def search(seqs, seq_off, lib_codes, k, context=None):
+    """(indptr int64 [R+1], indices int32) -- ascending unique library indices per read (GPU only)."""
+    ctx = context or _lib.default_context()
+    return ctx.kmer_search(seqs, seq_off, lib_codes, int(k))
+
+
+def write_output_bin(path, ids, indptr, indices):
+    """output.bin as kmer_searcher.cpp:98-130 writes it (header '<4sB3sQ', per record '<H' id length, id,
+    '<I' count, count x '<Q').  Ids must be printable ASCII, as there (:113-117)."""
+    with open(path, "wb", buffering=1 << 24) as f:
+        f.write(struct.pack("<4sB3sQ", b"KMER", 1, b"\0\0\0", len(ids)))
+        idx64 = np.asarray(indices).astype("<u8")
+        ptr = np.asarray(indptr).tolist()
+        for r, name in enumerate(ids):
+            if any(c < 32 or c > 126 for c in name):
+                raise ValueError("ID contains non-ASCII characters")
+            a, b = ptr[r], ptr[r + 1]
+            f.write(struct.pack("<H", len(name)))
+            f.write(name)
+            f.write(struct.pack("<I", b - a))
+            f.write(idx64[a:b].tobytes())
+
+
+def write_kmer_frequency_bin(path, indices, n_lib):
+    """kmer_frequency.bin (kmer_searcher.cpp:203-230): (index, number of reads containing it) as '<QQ' for
+    every library k-mer found in at least one read, ascending index."""
+    counts = np.bincount(np.asarray(indices, dtype=np.int64), minlength=int(n_lib))
+    nz = np.flatnonzero(counts)
+    out = np.empty((nz.size, 2), dtype="<u8")
+    out[:, 0] = nz
+    out[:, 1] = counts[nz]
+    out.tofile(path)
+
+
+def kmer_searcher(kmer_lib, input_reads, output_dir, k, threads=None, context=None):
+    """Drop-in for the command line `kmer_searcher <kmer_lib> <input> <output_dir> <k> <threads>`
+    (kmer_searcher.cpp:232-375).  `kmer_lib`: a path, a list of paths (read in order, like
+    `cat fwd rev | grep -v '^>'`; '>' header tokens are not k long and drop out by themselves unless a
+    count happens to have k digits -- so, as in the reference's pipeline, header lines are removed first).
+    Writes output_dir/output.bin and output_dir/kmer_frequency.bin; returns (ids, indptr, indices, n_lib)."""
+    paths = [kmer_lib] if isinstance(kmer_lib, (str, bytes, os.PathLike)) else list(kmer_lib)
+    texts = []
+    for p in paths:
+        with open(p, "rb") as f:
+            t = f.read()
+        texts.append(b"\n".join(l for l in t.split(b"\n") if not l.startswith(b">")) + b"\n")
+    codes = load_kmer_library(texts, k)
+    ids, seqs, off = read_sequences(input_reads)
+    indptr, indices = search(seqs, off, codes, k, context=context)
+    os.makedirs(output_dir, exist_ok=True)
+    write_output_bin(os.path.join(output_dir, "output.bin"), ids, indptr, indices)
+    write_kmer_frequency_bin(os.path.join(output_dir, "kmer_frequency.bin"), indices, codes.size)
+    return ids, indptr, indices, int(codes.size)

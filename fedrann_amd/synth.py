@@ -63,3 +63,46 @@ def synth(R, seed=602, m=200, q=0.85, c=30, Lcap=12_500_000, sigma=0.5, doubling
         strands = [0] * R
     return {"indptr": indptr, "indices": indices, "n_features": F, "counts": counts,
             "names": names, "strands": strands}
+
+
+def synth_sequences(n_reads, genome_len=200_000, mean_len=3000, k=15, sample=0.05, error=0.06, n_rate=2e-4,
+                    seed=602):
+    """Sequence-level synthetic input for the k-mer search: a random genome,
+    reads cut from either strand with substitution errors and a few N, and a k-mer library = a Bernoulli
+    sample of the genome's canonical k-mers followed by their reverse complements (what count_kmers.py
+    builds with jellyfish -C + awk + seqkit).  Returns dict(ids, seqs uint8, seq_off int64, fwd list of
+    bytes, rev list of bytes)."""
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGTN")] = list(b"TGCAN")
+    genome = alpha[rng.integers(0, 4, size=genome_len)]
+    lens = np.maximum(1, rng.lognormal(np.log(mean_len) - 0.125, 0.5, size=n_reads)).astype(np.int64)
+    lens = np.minimum(lens, genome_len)
+    starts = rng.integers(0, genome_len - lens + 1)
+    pieces = []
+    for s, n in zip(starts.tolist(), lens.tolist()):
+        r = genome[s:s + n].copy()
+        if rng.random() < 0.5:
+            r = comp[r[::-1]]
+        e = rng.random(n) < error
+        r[e] = alpha[rng.integers(0, 4, size=int(e.sum()))]
+        r[rng.random(n) < n_rate] = ord("N")
+        pieces.append(r)
+    seq_off = np.zeros(n_reads + 1, dtype=np.int64)
+    np.cumsum(lens, out=seq_off[1:])
+    seqs = np.concatenate(pieces) if pieces else np.zeros(0, dtype=np.uint8)
+    # canonical k-mers of the genome, sampled
+    win = np.lib.stride_tricks.sliding_window_view(genome, k)
+    pick = np.flatnonzero(rng.random(win.shape[0]) < sample)
+    fwd, seen = [], set()
+    for p in pick.tolist():
+        a = win[p].tobytes()
+        b = comp[win[p][::-1]].tobytes()
+        c = min(a, b)
+        if c not in seen:
+            seen.add(c)
+            fwd.append(c)
+    rev = [comp[np.frombuffer(x, dtype=np.uint8)[::-1]].tobytes() for x in fwd]
+    ids = [b"read_%07d" % i for i in range(n_reads)]
+    return {"ids": ids, "seqs": seqs, "seq_off": seq_off, "fwd": fwd, "rev": rev, "k": k}

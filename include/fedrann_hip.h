@@ -114,7 +114,9 @@ int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64
 #define FDR_KERNEL_KNN_RERANK 5    /* rest of the prefilter mode: fp16 conversion, key merge, certificate +
                                       exact fp32 re-rank (two timed spans per call) */
 #define FDR_KERNEL_KNN_DEDUP 6     /* duplicate-row classes: hash, sort, class tables, gathers, expansion */
-#define FDR_NUM_KERNELS 7
+#define FDR_KERNEL_KMER_SEARCH 7   /* k-mer search: library table build + the search passes */
+#define FDR_KERNEL_KMER_COMPACT 8  /* k-mer search: sort, de-duplication, row pointers */
+#define FDR_NUM_KERNELS 9
 int fdr_timing(fdr_ctx *ctx, int enable);
 int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out);
 /* ---- k-NN mode ---------------------------------------------------------------------------------
@@ -135,6 +137,20 @@ int fdr_last_unique(fdr_ctx *ctx, int *unique_targets, int *unique_queries);
 /* Prefilter mode only: number of query rows of the most recent k-NN call whose candidate set could
  * not be certified and that were therefore searched by the exact kernel. */
 int fdr_last_uncertified(fdr_ctx *ctx);
+
+/* ---- k-mer search on the GPU: reads x k-mer library -> per-read set of library indices -----------
+ * Replaces the reference's native tool kmer_searcher (kmer_searcher/kmer_searcher.cpp:232-375; called
+ * from fedrann/count_kmers.py:131-139).  lib_codes: the unique valid library k-mers in index order as
+ * 2-bit codes (A C G T = 0 1 2 3, first base in the most significant position; kmer_to_int :138-151).
+ * seqs: the reads' characters concatenated, read r = seqs[seq_off[r] .. seq_off[r+1]).  A character
+ * outside ACGTacgt makes every window that contains it invalid in the reference's particular way (see
+ * kmer_search.inc).  Output: CSR rows of ascending unique library indices per read (the reference
+ * writes them in hash-set order): indptr_out int64 [n_reads + 1] and *nnz_out from fdr_kmer_search,
+ * then the indices (int32 [nnz], kept on the device until then) from fdr_kmer_search_indices. */
+int fdr_kmer_search(fdr_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, int64_t n_reads,
+                    const uint64_t *lib_codes, int64_t n_lib, int32_t k, int64_t *indptr_out,
+                    int64_t *nnz_out);
+int fdr_kmer_search_indices(fdr_ctx *ctx, int32_t *indices_out);
 
 /* ---- kmer_searcher output.bin -> doubled binary CSR (host only: no context, no GPU) ---------------
  * Replaces fedrann/feature_extraction.py:108-140 (parse_kmer_searcher_output: header '<4sB3sQ' =

@@ -242,3 +242,173 @@ ORC_API int orc_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------
+ * kmer_searcher (the step upstream of the hot path).
+ *
+ * PARITY UNPINNED: kmer_searcher/kmer_searcher.cpp is the reference's only native file; it needs the
+ * un-vendored robin_hood.h submodule (unbuildable here, see oracle/Makefile) and its own test data pin
+ * an obsolete text format.  What follows restates its algorithm line by line, quirks included.
+ *
+ *  - kmer_to_int (kmer_searcher.cpp:138-151): 2 bits per base, A=0 C=1 G=2 T=3, either case; any other
+ *    character makes the k-mer invalid.
+ *  - library load (:262-279): whitespace-separated tokens; a token whose length is not k, an invalid
+ *    token, and a code seen before are skipped; the others get indices 0, 1, 2, ... in file order.
+ *  - scan of one read (:306-352): rolling code `cur = ((cur << 2) & mask) | base`; an invalid character
+ *    sets cur = UINT64_MAX (all ones) and the NEXT characters keep shifting into that, so until k valid
+ *    characters have passed the window reads as T...T + the characters since the invalid one.  No
+ *    look-up at an invalid character itself.  The first look-up happens after min(k, len) characters
+ *    (a read shorter than k is looked up once, left-padded with A = 0; an empty read looks up code 0).
+ *    The hits of a read form a SET (output order = hash order, unspecified; sorted ascending here).
+ * ------------------------------------------------------------------------------------------ */
+static uint64_t orc_mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+static int orc_base_code(unsigned char c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return -1;
+    }
+}
+
+typedef struct {
+    uint64_t *keys;  /* code + 1 (0 = empty) */
+    int64_t *vals;
+    uint64_t mask;
+} orc_kmer_table;
+
+static int orc_table_init(orc_kmer_table *t, int64_t n) {
+    uint64_t size = 16;
+    while (size < (uint64_t)(2 * n + 1)) size <<= 1;
+    t->keys = (uint64_t *)calloc(size, sizeof(uint64_t));
+    t->vals = (int64_t *)malloc(size * sizeof(int64_t));
+    t->mask = size - 1;
+    return t->keys && t->vals ? 0 : -1;
+}
+
+static void orc_table_free(orc_kmer_table *t) {
+    free(t->keys);
+    free(t->vals);
+}
+
+/* returns the stored index, or -1 after inserting (code -> idx) when insert != 0 */
+static int64_t orc_table_find(orc_kmer_table *t, uint64_t code, int insert, int64_t idx) {
+    uint64_t slot = orc_mix64(code) & t->mask;
+    for (;;) {
+        if (t->keys[slot] == 0) {
+            if (insert) {
+                t->keys[slot] = code + 1;
+                t->vals[slot] = idx;
+            }
+            return -1;
+        }
+        if (t->keys[slot] == code + 1) return t->vals[slot];
+        slot = (slot + 1) & t->mask;
+    }
+}
+
+/* Library text -> unique codes in index order.  Returns their number (or -1: out of memory, -2: cap). */
+ORC_API int64_t orc_kmer_library(const char *text, int64_t len, int k, uint64_t *codes_out, int64_t cap) {
+    if (k <= 0 || k > 31) return -3;
+    int64_t ntok = 0;
+    for (int64_t i = 0; i < len;) {  /* upper bound on tokens, for the table size */
+        while (i < len && (text[i] == ' ' || (text[i] >= '\t' && text[i] <= '\r'))) ++i;
+        if (i >= len) break;
+        ++ntok;
+        while (i < len && !(text[i] == ' ' || (text[i] >= '\t' && text[i] <= '\r'))) ++i;
+    }
+    orc_kmer_table t;
+    if (orc_table_init(&t, ntok)) return -1;
+    int64_t n = 0;
+    for (int64_t i = 0; i < len;) {
+        while (i < len && (text[i] == ' ' || (text[i] >= '\t' && text[i] <= '\r'))) ++i;
+        if (i >= len) break;
+        const int64_t b = i;
+        while (i < len && !(text[i] == ' ' || (text[i] >= '\t' && text[i] <= '\r'))) ++i;
+        if (i - b != k) continue;  /* :271 */
+        uint64_t code = 0;
+        int ok = 1;
+        for (int64_t j = b; j < i; ++j) {
+            const int c = orc_base_code((unsigned char)text[j]);
+            if (c < 0) {
+                ok = 0;
+                break;
+            }
+            code = (code << 2) | (uint64_t)c;
+        }
+        if (!ok) continue;  /* :273 code != UINT64_MAX */
+        if (orc_table_find(&t, code, 1, n) >= 0) continue;  /* :273 seen before */
+        if (n >= cap) {
+            orc_table_free(&t);
+            return -2;
+        }
+        codes_out[n++] = code;
+    }
+    orc_table_free(&t);
+    return n;
+}
+
+static int orc_cmp_i32(const void *a, const void *b) {
+    const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* Reads (concatenated bytes + offsets) x library codes -> per-read sorted unique library indices.
+ * Returns nnz; if nnz > cap nothing beyond indptr is valid (call again with a larger buffer). */
+ORC_API int64_t orc_kmer_search(const char *seqs, const int64_t *off, int64_t n_reads, const uint64_t *codes,
+                                int64_t n_lib, int k, int64_t *indptr, int32_t *indices, int64_t cap) {
+    if (k <= 0 || k > 31) return -3;
+    orc_kmer_table t;
+    if (orc_table_init(&t, n_lib)) return -1;
+    for (int64_t i = 0; i < n_lib; ++i) (void)orc_table_find(&t, codes[i], 1, i);
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    int64_t nnz = 0, hcap = 1024;
+    int32_t *hits = (int32_t *)malloc((size_t)hcap * sizeof(int32_t));
+    indptr[0] = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const unsigned char *s = (const unsigned char *)seqs + off[r];
+        const int64_t len = off[r + 1] - off[r];
+        int64_t nh = 0;
+        uint64_t cur = 0;
+        for (int64_t i = 0; i < len || i == 0; ++i) {
+            if (i < len) {  /* (an empty read still does the first look-up, with cur = 0) */
+                const int c = orc_base_code(s[i]);
+                cur = (cur << 2) & mask;
+                if (c < 0) cur = UINT64_MAX; else cur |= (uint64_t)c;
+            }
+            const int lookup = (i >= k - 1) || (i == len - 1) || len == 0;  /* :323 after the init loop, :339 */
+            if (lookup && cur != UINT64_MAX) {
+                const int64_t idx = orc_table_find(&t, cur, 0, 0);
+                if (idx >= 0) {
+                    if (nh == hcap) {
+                        hcap *= 2;
+                        hits = (int32_t *)realloc(hits, (size_t)hcap * sizeof(int32_t));
+                    }
+                    hits[nh++] = (int32_t)idx;
+                }
+            }
+            if (len == 0) break;
+        }
+        qsort(hits, (size_t)nh, sizeof(int32_t), orc_cmp_i32);
+        int64_t u = 0;
+        for (int64_t i = 0; i < nh; ++i)
+            if (i == 0 || hits[i] != hits[i - 1]) {
+                if (nnz + u < cap) indices[nnz + u] = hits[i];
+                ++u;
+            }
+        nnz += u;
+        indptr[r + 1] = nnz;
+    }
+    free(hits);
+    orc_table_free(&t);
+    return nnz;
+}

@@ -235,3 +235,81 @@ def overlaps_tsv(indices, distances, read_names, strands):
     buf = io.StringIO()
     df.to_csv(buf, sep="\t", index=False)
     return buf.getvalue()
+
+
+# --------------------------------------------------------------------------------------------
+# kmer_searcher (kmer_searcher/kmer_searcher.cpp) -- PARITY UNPINNED, see fedrann_oracle.c
+# --------------------------------------------------------------------------------------------
+def read_sequences(path):
+    """kmer_searcher.cpp:153-200, line by line.  FASTA unless the first line starts with '@'.
+    FASTA: id = header up to the first space/tab, sequence = the following lines concatenated (only the
+    '\\n' is stripped: a '\\r' stays in the sequence and is an invalid character); a header with an empty
+    id does not start a record.  FASTQ: id = the whole header line after '@', sequence = the next line,
+    two lines skipped.  Returns (ids, sequences) as lists of bytes."""
+    ids, seqs = [], []
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()  # getline does not yield a final empty piece
+    is_fastq = bool(lines) and lines[0][:1] == b"@"
+    cur_id, cur_seq, i = b"", b"", 0
+    while i < len(lines):
+        line = lines[i]
+        i += 1
+        if not line:
+            continue
+        if not is_fastq:
+            if line[:1] == b">":
+                if cur_id:
+                    ids.append(cur_id)
+                    seqs.append(cur_seq)
+                head = line[1:]
+                cut = min([p for p in (head.find(b" "), head.find(b"\t")) if p >= 0], default=-1)
+                cur_id = head if cut < 0 else head[:cut]
+                cur_seq = b""
+            else:
+                cur_seq += line
+        elif line[:1] == b"@":
+            cur_id = line[1:]
+            cur_seq = lines[i] if i < len(lines) else b""
+            i += 3
+            ids.append(cur_id)
+            seqs.append(cur_seq)
+    if not is_fastq and cur_id:
+        ids.append(cur_id)
+        seqs.append(cur_seq)
+    return ids, seqs
+
+
+def kmer_library(text, k):
+    """Library text (bytes) -> uint64 codes of the unique valid k-mers in index order (:262-279)."""
+    buf = np.frombuffer(bytes(text), dtype=np.uint8)
+    cap = max(16, len(text) // max(k, 1) + 16)
+    codes = np.empty(cap, dtype=np.uint64)
+    L = lib()
+    L.orc_kmer_library.restype = ctypes.c_int64
+    L.orc_kmer_library.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
+    n = L.orc_kmer_library(buf.ctypes.data if buf.size else None, buf.size, int(k), _p(codes), cap)
+    if n < 0:
+        raise ValueError("orc_kmer_library failed (%d)" % n)
+    return codes[:n].copy()
+
+
+def kmer_search(seqs, codes, k):
+    """Per-read sorted unique library indices (:306-352).  seqs: list of bytes.  Returns (indptr, indices)."""
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    cat = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    codes = np.ascontiguousarray(codes, dtype=np.uint64)
+    indptr = np.empty(len(seqs) + 1, dtype=np.int64)
+    L = lib()
+    L.orc_kmer_search.restype = ctypes.c_int64
+    L.orc_kmer_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    cap = max(1024, int(off[-1]) + len(seqs))
+    indices = np.empty(cap, dtype=np.int32)
+    nnz = L.orc_kmer_search(cat.ctypes.data if cat.size else None, _p(off), len(seqs), _p(codes), codes.size, int(k),
+                            _p(indptr), _p(indices), cap)
+    if nnz < 0 or nnz > cap:
+        raise ValueError("orc_kmer_search failed (%d)" % nnz)
+    return indptr, indices[:nnz].copy()

@@ -77,3 +77,37 @@ def test_cli_from_feature_matrix_npz(tmp_path, oracle):
     E = oracle.embed(s["indptr"], s["indices"], P, s["n_features"], 128)
     idx, dist = oracle.knn(E, 20)
     assert got == oracle.overlaps_tsv(idx, dist, s["names"], s["strands"])
+
+
+def test_cli_from_reads_and_kmer_library(tmp_path, oracle):
+    """-i reads.fasta + --kmer-library: k-mer search, loader, embed, k-NN and writer all on this build;
+    the oracle side restates kmer_searcher.cpp, the reference's parser and its writer."""
+    from fedrann_amd.synth import synth_sequences
+    k = 15
+    s = synth_sequences(700, genome_len=120_000, mean_len=2500, k=k, sample=0.04, seed=31)
+    rng = np.random.default_rng(2)
+    counts = rng.integers(2, 40, size=len(s["fwd"]))
+    lib = tmp_path / "fwd_kmer_library.fasta"
+    lib.write_bytes(b"".join(b">%d\n%s\n" % (int(c), x) for c, x in zip(counts, s["fwd"])))
+    reads = [bytes(s["seqs"][s["seq_off"][i]:s["seq_off"][i + 1]]) for i in range(700)]
+    fa = tmp_path / "reads.fasta"
+    fa.write_bytes(b"".join(b">%s len=%d\n%s\n" % (i, len(r), r) for i, r in zip(s["ids"], reads)))
+    out_dir = tmp_path / "out"
+    cli.main(["-i", str(fa), "-k", str(k), "-o", str(out_dir), "-n", "128", "--nndescent-n-neighbors", "20",
+              "--kmer-library", str(lib), "--keep-intermediates"])
+    got = open(out_dir / "overlaps.tsv", newline="").read()
+    L = len(s["fwd"])
+    codes = oracle.kmer_library(b"\n".join(s["fwd"] + s["rev"]), k)
+    ip, ix = oracle.kmer_search(reads, codes, k)
+    rows = []
+    for r in range(700):
+        idx = ix[ip[r]:ip[r + 1]].astype(np.int64)
+        rows.append(idx.tolist())
+        rows.append(np.where(idx < L, idx + L, idx - L).tolist())
+    P = oracle.precompute_matrix(counts, 128)
+    indptr, indices = oracle.rows_to_csr(rows)
+    E = oracle.embed(indptr, indices, P, 2 * L, 128)
+    idx, dist = oracle.knn(E, 20)
+    names = [i.decode() for i in s["ids"] for _ in (0, 1)]
+    assert got == oracle.overlaps_tsv(idx, dist, names, [0, 1] * 700)
+    assert os.path.exists(out_dir / "temp" / "kmer_searcher" / "output.bin")

@@ -1,0 +1,100 @@
+"""fdr_kmer_search (GPU) against the oracle's restatement of kmer_searcher.cpp: identical per-read index
+sets, incl. the reference's treatment of invalid characters, short and empty reads."""
+import numpy as np
+import pytest
+
+from fedrann_amd import feature_extraction as fx
+from fedrann_amd import kmer_search as ks
+from fedrann_amd.synth import synth_sequences
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads(seqs, off):
+    return [bytes(seqs[off[i]:off[i + 1]]) for i in range(off.size - 1)]
+
+
+def _assert_same(ctx, oracle, seqs, off, codes, k):
+    ip, ix = ctx.kmer_search(seqs, off, codes, k)
+    wp, wx = oracle.kmer_search(_reads(seqs, off), codes, k)
+    assert np.array_equal(ip, wp), "row pointers differ"
+    assert np.array_equal(ix, wx), "library indices differ"
+    return ip, ix
+
+
+def test_kmer_search_handcrafted_quirks(ctx, oracle):
+    codes = oracle.kmer_library(b"ACG CGT TTT AAC AAA", 3)
+    reads = [b"ACGT", b"", b"AC", b"ANTTTA", b"acgt", b"NA", b"", b"TTTTTTTTTT", b"N", b"ACGNACG"]
+    off = np.zeros(len(reads) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    seqs = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    _assert_same(ctx, oracle, seqs, off, codes, 3)
+    _assert_same(ctx, oracle, seqs, off, codes[:0], 3)          # empty library
+    _assert_same(ctx, oracle, seqs[:0], np.zeros(4, np.int64), codes, 3)  # only empty reads
+
+
+@pytest.mark.parametrize("k,n_reads,mean_len", [(15, 3000, 3000), (21, 1500, 5000), (31, 800, 8000), (5, 400, 300)])
+def test_kmer_search_synthetic_reads(ctx, oracle, k, n_reads, mean_len):
+    s = synth_sequences(n_reads, genome_len=300_000, mean_len=mean_len, k=k, sample=0.05, n_rate=1e-3,
+                        seed=100 + k)
+    codes = ks.load_kmer_library([b"\n".join(s["fwd"]) + b"\n", b"\n".join(s["rev"]) + b"\n"], k)
+    assert np.array_equal(codes, oracle.kmer_library(b"\n".join(s["fwd"] + s["rev"]) + b"\n", k))
+    seqs, off = s["seqs"].copy(), s["seq_off"]
+    seqs[::997] |= 0x20  # some lower case
+    ip, ix = _assert_same(ctx, oracle, seqs, off, codes, k)
+    assert ix.size > n_reads  # the library really is hit
+
+
+def test_kmer_search_short_reads_and_chunk_boundaries(ctx, oracle):
+    """Thousands of reads shorter than, equal to and just above k, so that read boundaries fall everywhere
+    inside the 4 KiB chunks and the 16-position thread stretches."""
+    rng = np.random.default_rng(9)
+    k = 15
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=50_000)]
+    lens = rng.integers(0, 40, size=20_000)
+    starts = rng.integers(0, genome.size - 40, size=lens.size)
+    pieces = [genome[a:a + n] for a, n in zip(starts, lens)]
+    off = np.zeros(lens.size + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lens)
+    seqs = np.concatenate(pieces).copy()
+    seqs[rng.random(seqs.size) < 0.003] = ord("N")
+    win = np.lib.stride_tricks.sliding_window_view(genome, k)[::7]
+    text = b"\n".join(w.tobytes() for w in win) + b"\nAAAAAAAAAAAAAAA\n"  # + the code an empty read looks up
+    codes = ks.load_kmer_library(text, k)
+    _assert_same(ctx, oracle, seqs, off, codes, k)
+
+
+def test_kmer_search_hit_buffer_regrow(ctx, oracle):
+    """A library holding most 9-mers: ~80 % of the 3 M windows hit, more than the first guess of the hit
+    buffer (max(2^20, positions / 4)), so the pass is repeated with the exact size."""
+    rng = np.random.default_rng(10)
+    k = 9
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=3_000_000)]
+    text = b"\n".join(w.tobytes() for w in np.lib.stride_tricks.sliding_window_view(genome[:400_000], k)) + b"\n"
+    codes = ks.load_kmer_library(text, k)
+    off = np.arange(0, genome.size + 1, 10_000, dtype=np.int64)
+    ip, ix = _assert_same(ctx, oracle, genome, off, codes, k)
+    assert ix.size > 300 * 1000  # (unique per read; the raw hits are ~2.4 M)
+
+
+def test_kmer_searcher_drop_in_writes_reference_files(ctx, oracle, tmp_path):
+    """kmer_searcher(): library files + FASTA in, output.bin + kmer_frequency.bin out; output.bin goes
+    through the same loader as the reference tool's file would."""
+    s = synth_sequences(500, genome_len=80_000, mean_len=2000, k=15, seed=77)
+    fwd, rev, fa = tmp_path / "fwd.fasta", tmp_path / "rev.fasta", tmp_path / "reads.fasta"
+    fwd.write_bytes(b"".join(b">%d\n%s\n" % (3 + i % 5, x) for i, x in enumerate(s["fwd"])))
+    rev.write_bytes(b"".join(b">%d\n%s\n" % (3 + i % 5, x) for i, x in enumerate(s["rev"])))
+    reads = _reads(s["seqs"], s["seq_off"])
+    fa.write_bytes(b"".join(b">%s extra\n%s\n" % (i, b"\n".join(r[j:j + 70] for j in range(0, len(r), 70)))
+                            for i, r in zip(s["ids"], reads)))
+    ids, ip, ix, n_lib = ks.kmer_searcher([str(fwd), str(rev)], str(fa), str(tmp_path / "out"), 15, context=ctx)
+    assert ids == s["ids"] and n_lib == 2 * len(s["fwd"])
+    codes = oracle.kmer_library(b"\n".join(s["fwd"] + s["rev"]), 15)
+    wp, wx = oracle.kmer_search(reads, codes, 15)
+    assert np.array_equal(ip, wp) and np.array_equal(ix, wx)
+    F = 2 * len(s["fwd"])
+    ip2, ix2, names, strands = fx.build_feature_csr(str(tmp_path / "out" / "output.bin"), F)
+    assert names[0::2] == [x.decode() for x in ids]
+    assert np.array_equal(ix2[ip2[0]:ip2[1]], ix[ip[0]:ip[1]])
+    freq = np.fromfile(str(tmp_path / "out" / "kmer_frequency.bin"), dtype="<u8").reshape(-1, 2)
+    assert int(freq[:, 1].sum()) == ix.size

@@ -1,0 +1,103 @@
+"""Host side of the k-mer search (no GPU): library and read parsers against the oracle's line-by-line
+restatement of kmer_searcher.cpp, output.bin writer round trip through the native loader."""
+import struct
+
+import numpy as np
+import pytest
+
+from fedrann_amd import feature_extraction as fx
+from fedrann_amd import kmer_search as ks
+
+
+def test_library_loader_matches_oracle(oracle):
+    rng = np.random.default_rng(3)
+    toks = []
+    for _ in range(4000):
+        n = int(rng.choice([15, 15, 15, 15, 14, 16, 3]))
+        t = "".join(rng.choice(list("ACGTacgt"), size=n))
+        if rng.random() < 0.02:
+            t = t[:5] + "N" + t[6:]
+        toks.append(t)
+    toks += toks[:50] + [">15", ">123456789012345", "ACGTACGTACGTACG", "acgtacgtacgtacg"]  # repeats, a 15-char header
+    text = ("\n".join(toks[:2000]) + "\t \r\n" + " ".join(toks[2000:]) + "\n").encode()
+    for k in (15, 3, 16):
+        got = ks.load_kmer_library(text, k)
+        assert np.array_equal(got, oracle.kmer_library(text, k))
+    assert ks.load_kmer_library([b"ACG\n", b"CGT\nACG"], 3).tolist() == [6, 27]
+    assert ks.load_kmer_library(b"", 5).size == 0
+    with pytest.raises(ValueError):
+        ks.load_kmer_library(b"ACGT", 32)
+
+
+def _check_reader(path, oracle):
+    ids, seqs, off = ks.read_sequences(str(path))
+    o_ids, o_seqs = oracle.read_sequences(str(path))
+    assert ids == o_ids
+    assert [bytes(seqs[off[i]:off[i + 1]]) for i in range(len(ids))] == o_seqs
+
+
+def test_read_sequences_matches_oracle(tmp_path, oracle):
+    rng = np.random.default_rng(4)
+    lines = [b"stray line before any header"]
+    for i in range(300):
+        head = b">r%d" % i
+        if i % 7 == 0:
+            head += b" description here"
+        if i % 11 == 0:
+            head += b"\tx"
+        if i == 13:
+            head = b">"          # empty id: the record is dropped
+        if i == 14:
+            head = b"> onlydesc"  # empty id too
+        lines.append(head)
+        for _ in range(int(rng.integers(0, 4))):
+            lines.append(bytes(rng.choice(list(b"ACGTNacgt"), size=int(rng.integers(0, 80))).astype(np.uint8)))
+        if i % 17 == 0:
+            lines.append(b"ACGT\r")
+    for tail in (b"\n", b"", b"\n\n"):
+        p = tmp_path / "a.fa"
+        p.write_bytes(b"\n".join(lines) + tail)
+        _check_reader(p, oracle)
+    fq = []
+    for i in range(100):
+        s = bytes(rng.choice(list(b"ACGTN"), size=int(rng.integers(0, 50))).astype(np.uint8))
+        fq += [b"@q%d some text" % i, s, b"+", b"@" * len(s)]  # quality lines that look like headers
+    p = tmp_path / "a.fq"
+    p.write_bytes(b"\n".join(fq) + b"\n")
+    _check_reader(p, oracle)
+    p.write_bytes(b"")
+    assert ks.read_sequences(str(p))[0] == []
+    p.write_bytes(b"\n>x\nAC\n")  # an empty first line: FASTA
+    _check_reader(p, oracle)
+
+
+def test_output_bin_writer_round_trip(tmp_path):
+    rng = np.random.default_rng(5)
+    F = 2000
+    ids = [b"read/%d" % i for i in range(200)]
+    rows = [np.sort(rng.choice(F, size=int(rng.integers(0, 30)), replace=False)) for _ in ids]
+    indptr = np.zeros(len(ids) + 1, dtype=np.int64)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    indices = np.concatenate(rows).astype(np.int32)
+    p = tmp_path / "output.bin"
+    ks.write_output_bin(str(p), ids, indptr, indices)
+    ip2, ix2, names, strands = fx.build_feature_csr(str(p), F)
+    assert names[0::2] == [x.decode() for x in ids] and strands[:2] == [0, 1]
+    for r, want in enumerate(rows):
+        assert ix2[ip2[2 * r]:ip2[2 * r + 1]].tolist() == want.tolist()
+    with pytest.raises(ValueError):
+        ks.write_output_bin(str(p), [b"bad\xffid"], [0, 0], [])
+    ks.write_kmer_frequency_bin(str(tmp_path / "f.bin"), indices, F)
+    freq = np.fromfile(str(tmp_path / "f.bin"), dtype="<u8").reshape(-1, 2)
+    want = np.bincount(indices, minlength=F)
+    assert np.array_equal(freq[:, 0], np.flatnonzero(want)) and np.array_equal(freq[:, 1], want[want > 0])
+
+
+def test_kmer_search_oracle_quirks(oracle):
+    """The restated quirks themselves (kmer_searcher.cpp:306-352): window after an invalid character,
+    reads shorter than k, the empty read, lower case."""
+    codes = oracle.kmer_library(b"ACG CGT TTT AAC AAA", 3)
+    assert codes.tolist() == [6, 27, 63, 1, 0]
+    ip, ix = oracle.kmer_search([b"ACGT", b"", b"AC", b"ANTTTA", b"acgt", b"NA"], codes, 3)
+    assert ip.tolist() == [0, 2, 3, 4, 5, 7, 7]
+    assert ix.tolist() == [0, 1, 4, 3, 2, 0, 1]
