@@ -11,6 +11,9 @@ Pinned against the reference's own outputs (tests/golden/, made by tests/golden/
     overlaps_tsv       <- __main__.py:261-300, :385         PINNED (overlaps_{edge,rand}.tsv)
     knn                <- nearest_neighbors.py:39-55        PARITY UNPINNED (pynndescent absent; see
                           the header of fedrann_oracle.c)
+    read_sequences / kmer_library / kmer_search
+                       <- kmer_searcher/kmer_searcher.cpp   PARITY UNPINNED (needs the un-vendored
+                          robin_hood.h; its own test data pin an obsolete format)
 """
 import ctypes
 import io
