@@ -64,9 +64,11 @@ def cpu_budget():
     return n
 
 
-def cpu_baseline(s, P, d, k, target_seconds):
+def cpu_baseline(s, P, d, k, target_seconds, gpu_result=None):
     """Time the CPU oracle on a bounded sample: embed + normalise ALL rows (they are the targets),
-    then k-NN for as many query rows as fit the time budget; extrapolate linearly in queries."""
+    then k-NN for as many query rows as fit the time budget; extrapolate linearly in queries.
+    `gpu_result` = (idx, dist) numpy arrays of the GPU run's first rows: the oracle's rows are compared
+    with them bit for bit (reported as `parity_sample`; the measurement itself is unaffected)."""
     import numpy as np
     from oracle import oracle as O
     O.set_num_threads(cpu_budget())  # (libgomp is already loaded by torch: the env var would be too late)
@@ -86,10 +88,17 @@ def cpu_baseline(s, P, d, k, target_seconds):
     nq = int(min(n, max(probe, target_seconds / max(t_probe / probe, 1e-9))))
     nq = max(64, nq // 64 * 64) if n >= 64 else n
     t0 = time.perf_counter()
-    O.knn_normalized(Eh[:nq], zero[:nq], Eh, zero, k)
+    o_idx, o_dist = O.knn_normalized(Eh[:nq], zero[:nq], Eh, zero, k)
     t_knn = time.perf_counter() - t0
     est_total = t_embed + t_norm + t_knn * n / nq
+    parity = None
+    if gpu_result is not None:
+        m = min(nq, gpu_result[0].shape[0])
+        same = bool(np.array_equal(gpu_result[0][:m], o_idx[:m])) and bool(
+            np.array_equal(gpu_result[1][:m].view(np.uint32), o_dist[:m].view(np.uint32)))
+        parity = {"rows": int(m), "identical_indices_and_distance_bits": same}
     return {
+        "parity_sample": parity,
         "value": n * k / est_total, "unit": "read-pairs/s", "cores": cores, "kind": "port",
         "sample": ("oracle/fedrann_oracle.c (exact fp32 cosine k-NN, AVX2+OpenMP): embed+normalise all "
                    "%d rows (%.2fs+%.2fs), k-NN of %d of %d query rows vs all targets in %.2fs, "
@@ -265,7 +274,9 @@ def main():
             other["roofline"] = mfma_roofline(other["kernels_ms"], other["mode"] == "prefilter")
             result["other_mode"] = other
         if world == 1 and args.cpu_baseline_seconds > 0:
-            result["cpu_baseline"] = cpu_baseline(s, P, d, k, args.cpu_baseline_seconds)
+            m = min(nloc, 1 << 17)
+            result["cpu_baseline"] = cpu_baseline(s, P, d, k, args.cpu_baseline_seconds,
+                                                  gpu_result=(out[0][:m].cpu().numpy(), out[1][:m].cpu().numpy()))
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))
