@@ -746,7 +746,7 @@ __device__ __forceinline__ unsigned reglist_round(RegList<LH> &L, unsigned cand,
 // integer max3 tree on the accumulator bits (10 instructions per tile, group maxima as by-products),
 // stage parity unrolled so that every ds_read address is a register + immediate, LDS-DMA sources as
 // 32-bit offsets advanced by a constant, the wave number in an SGPR.
-template <int DP, int NQ, int NW, int WPS, int U, int LH>
+template <int DP, int NQ, int NW, int WPS, int U, int LH, bool PAIRED = false>
 __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
     const _Float16 *__restrict__ Qh, int nq, const _Float16 *__restrict__ Th, int nt, int t_base,
     SegBounds segs, int K, int nq_pad, u64 *__restrict__ partial, unsigned *__restrict__ tau_shared,
@@ -931,9 +931,53 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
+    // score one finished tile of query set n (hot: a max tree and one compare; cold: offer())
+    auto score = [&](const f32x16 &av, int n, int t) __attribute__((always_inline)) {
+        int g[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            g[q4] = max(max(max(__float_as_int(av[4 * q4]), __float_as_int(av[4 * q4 + 1])),
+                            __float_as_int(av[4 * q4 + 2])),
+                        __float_as_int(av[4 * q4 + 3]));
+        const int mx = max(max(max(g[0], g[1]), g[2]), g[3]);
+        const bool dbgc = (dbg & 2) != 0;
+        DBG_COUNT(0);
+        if (dbg & 1) {  // timing experiment: MFMA + fast path only
+            if (mx == 0x7fffffff) cthr[n] = mx;
+        } else if (__any(mx >= cthr[n])) {
+            int lrow = t * 32 + 4 * h;  // row - segment start of this lane's first row
+            int nvalid = t_end - (t_begin + t * 32);
+            asm volatile("" : "+v"(lrow), "+s"(nvalid));  // keep the cold block's set-up cold
+            offer(av, g, L[n], q0[n], q1[n], flim[n], cthr[n], lrow, nvalid);
+            cthr[n] = rethreshold(L[n], flim[n]);
+        }
+    };
+    constexpr bool PAIR = PAIRED && NCH == 1 && U == 2 && NQ == 1;  // the stage's two tiles as two MFMA chains
     auto stage_body = [&](auto par_c, int it) {
         constexpr int par = decltype(par_c)::value;
         if (it + 1 < nstages) issue_stage(std::integral_constant<int, par ^ 1>{});  // lands before the barrier below
+        if constexpr (PAIR) {
+            // two independent accumulator chains (a dependent 32x32x16 MFMA waits for its predecessor's
+            // result; the other tile's MFMA fills that slot); both share every query fragment
+            const int t0 = 2 * it;
+            if (t0 < nunits) {
+                f32x16 accB;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[0][r] = 0.f;
+                    accB[r] = 0.f;
+                }
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const f16x8 a0 = *(lds_f16x8 *)(size_t)(fa[s8] + (unsigned)(par * STAGE_BYTES));
+                    const f16x8 a1 = *(lds_f16x8 *)(size_t)(fa[s8] + (unsigned)(par * STAGE_BYTES + UNIT_BYTES));
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0][s8], acc[0], 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[0][s8], accB, 0, 0, 0);
+                }
+                score(acc[0], 0, t0);
+                if (t0 + 1 < nunits) score(accB, 0, t0 + 1);  // (the second unit of a last, odd stage is padding)
+            }
+        } else {
 #pragma unroll
         for (int uu = 0; uu < U; ++uu) {
             constexpr int dummy = 0;
@@ -971,28 +1015,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void knn_prefilter_kernel(
                 if (c == NCH - 1) {
                     // acc[n][r] = similarity of query j of set n with tile row (r&3) + 8*(r>>2) + 4*h
 #pragma unroll
-                    for (int n = 0; n < NQ; ++n) {
-                        int g[4];
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4)
-                            g[q4] = max(max(max(__float_as_int(acc[n][4 * q4]), __float_as_int(acc[n][4 * q4 + 1])),
-                                            __float_as_int(acc[n][4 * q4 + 2])),
-                                        __float_as_int(acc[n][4 * q4 + 3]));
-                        const int mx = max(max(max(g[0], g[1]), g[2]), g[3]);
-                        const bool dbgc = (dbg & 2) != 0;
-                        DBG_COUNT(0);
-                        if (dbg & 1) {  // timing experiment: MFMA + fast path only
-                            if (mx == 0x7fffffff) cthr[n] = mx;
-                        } else if (__any(mx >= cthr[n])) {
-                            int lrow = t * 32 + 4 * h;  // row - segment start of this lane's first row
-                            int nvalid = t_end - (t_begin + t * 32);
-                            asm volatile("" : "+v"(lrow), "+s"(nvalid));  // keep the cold block's set-up cold
-                            offer(acc[n], g, L[n], q0[n], q1[n], flim[n], cthr[n], lrow, nvalid);
-                            cthr[n] = rethreshold(L[n], flim[n]);
-                        }
-                    }
+                    for (int n = 0; n < NQ; ++n) score(acc[n], n, t);
                 }
             }
+        }
         }
         if ((it & 15) == 15) {
 #pragma unroll
@@ -2409,7 +2435,13 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     } while (0)
     if (dp == 128 && sh.nw == 8 && sh.nq == 2) FDR_LAUNCH_PRE(128, 2, 8, 2, 2);
     else if (dp == 128 && sh.nw == 8) FDR_LAUNCH_PRE(128, 1, 8, 4, 2);
-    else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
+    else if (dp == 128 && kp <= 32 && !(getenv("FDR_KNN_PAIR") && atoi(getenv("FDR_KNN_PAIR")) == 0)) {
+        // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
+        // <= 128 VGPRs.  FDR_KNN_PAIR=0: development knob, one chain)
+        hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)p.nqb, (unsigned)p.nseg),
+                           dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad,
+                           d_partial, d_shared, ib, pdbg);
+    } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
     else if (dp == 256 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 3, 2);
     else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
     else if (sh.nw == 8) FDR_LAUNCH_PRE(512, 1, 8, 2, 2);
