@@ -2561,6 +2561,7 @@ static int launch_knn_mode(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_q
         d_Qhat && d_qzero && d_That && d_tzero && d_idx && d_dist && d_ws)
         return launch_knn_prefilter(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx,
                                     d_dist, d_ws, ws_bytes, st);
+    ctx->last_flagged = 0;  // (exact mode certifies nothing)
     return launch_knn_exact(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
                             d_ws, ws_bytes, st);
 }
