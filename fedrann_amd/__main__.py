@@ -247,12 +247,21 @@ def main(argv=None):
         logger.info("--- 1b. k-mer search on the GPU ---")
         args.kmer_searcher_output = _gpu_kmer_search(args.input, args.kmer_library, args.kmer_size, temp_dir)
         have_ks = True
+    if args.input and not args.kmer_library and not have_ks and not have_fm:
+        # the whole stage 1 on the GPU (count_kmers.py:52-148): canonical k-mer counts, threshold, Bernoulli
+        # sample, reverse library, search
+        from .count_kmers import run_kmer_searcher
+        logger.info("--- 1. Counter kmers (GPU) ---")
+        args.kmer_searcher_output, n_features, read_count = run_kmer_searcher(
+            input_path=args.input, k=args.kmer_size, sample_fraction=args.kmer_sample_fraction,
+            min_multiplicity=args.kmer_min_multiplicity)
+        logger.debug("kmer_searcher n_features: %d, reads: %d", n_features, read_count)
+        args.kmer_library = join(temp_dir, "fwd_kmer_library.fasta")
+        have_ks = True
     if have_ks == have_fm:
         raise SystemExit(
-            "give exactly one of --kmer-searcher-output (+ --kmer-library), -i reads (+ --kmer-library) or "
-            "--feature-matrix (+ --kmer-counts).  K-mer counting and sampling (jellyfish + awk, the first "
-            "half of stage 1 of the reference) are not part of this build: run the reference with "
-            "--keep-intermediates and pass its temp/fwd_kmer_library.fasta here.")
+            "give exactly one of -i reads, -i reads + --kmer-library, --kmer-searcher-output + --kmer-library, "
+            "or --feature-matrix + --kmer-counts")
     if have_ks and not args.kmer_library:
         raise SystemExit("--kmer-searcher-output needs --kmer-library")
     if have_fm and not args.kmer_counts:

@@ -16,7 +16,8 @@ SYMBOLS = (
     "fdr_projection_load", "fdr_embed", "fdr_knn", "fdr_embed_knn", "fdr_embed_dev",
     "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_timing", "fdr_timing_read",
     "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_last_unique", "fdr_kmer_output_scan",
-    "fdr_kmer_output_load", "fdr_kmer_search", "fdr_kmer_search_indices",
+    "fdr_kmer_output_load", "fdr_kmer_search", "fdr_kmer_search_indices", "fdr_kmer_count",
+    "fdr_kmer_count_fetch",
 )
 FDR_MAX_K = 64
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
@@ -86,6 +87,8 @@ def load_library():
     L.fdr_kmer_output_load.argtypes = [ctypes.c_char_p, i64, i32, vp, vp, vp, vp]
     L.fdr_kmer_search.argtypes = [vp, vp, vp, i64, vp, i64, i32, vp, p64]
     L.fdr_kmer_search_indices.argtypes = [vp, vp]
+    L.fdr_kmer_count.argtypes = [vp, vp, vp, i64, i32, i64, p64]
+    L.fdr_kmer_count_fetch.argtypes = [vp, vp, vp]
     L.fdr_timing.argtypes = [vp, ctypes.c_int]
     L.fdr_timing_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(ctypes.c_float)]
@@ -200,6 +203,18 @@ class Context:
         indices = np.empty(nnz.value, dtype=np.int32)
         self._check(self._L.fdr_kmer_search_indices(self._h, indices.ctypes.data), "fdr_kmer_search_indices")
         return indptr, indices
+
+    def kmer_count(self, seqs, seq_off, k, min_count=1):
+        """Canonical k-mers with >= min_count occurrences: (codes uint64 ascending, counts uint64)."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        n = ctypes.c_int64()
+        self._check(self._L.fdr_kmer_count(self._h, seqs.ctypes.data, seq_off.ctypes.data, seq_off.size - 1, int(k),
+                                           int(min_count), ctypes.byref(n)), "fdr_kmer_count")
+        codes = np.empty(n.value, dtype=np.uint64)
+        counts = np.empty(n.value, dtype=np.uint64)
+        self._check(self._L.fdr_kmer_count_fetch(self._h, codes.ctypes.data, counts.ctypes.data), "fdr_kmer_count_fetch")
+        return codes, counts
 
     def last_unique(self):
         """(unique target rows, unique query rows) searched by the last k-NN call."""

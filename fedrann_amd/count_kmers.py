@@ -1,0 +1,91 @@
+"""Stage 1 of the reference pipeline on the GPU: canonical k-mer counting, sampling, k-mer search.
+
+Mirror of fedrann/count_kmers.py:52-148 (`run_kmer_searcher`), whose work is done there by third-party
+binaries:
+
+    jellyfish count -m k -s 10G -t T -C reads.fasta      -> fdr_kmer_count   (canonical counts)
+    jellyfish dump -L min_multiplicity                    -> the min_count argument
+    awk 'BEGIN{srand(seed)} ... rand() > 1-p'              -> numpy Generator(PCG64(seed)).random() > 1-p
+    seqkit seq -r -p -t DNA fwd > rev                      -> reverse complement, same order
+    cat fwd rev | grep -v '^>' | kmer_searcher ...         -> fedrann_amd.kmer_search.kmer_searcher
+
+What cannot be reproduced bit for bit, by construction: jellyfish dumps in its hash-table order and awk's
+rand() stream depends on the awk implementation, so WHICH k-mers are sampled and how they are numbered
+differs from a reference run (any run of the reference on another awk differs in the same way).  The
+feature order only names the features; everything downstream of fwd_kmer_library.fasta is exact again.
+Here the library is in ascending code order (= lexicographic k-mer order).
+"""
+import os
+from os.path import join
+
+import numpy as np
+
+from . import _lib, global_variables
+from .kmer_search import kmer_searcher, read_sequences
+
+_BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def codes_to_kmers(codes, k):
+    """uint64 2-bit codes -> uint8 [n, k] of 'ACGT' characters (first base in the highest position)."""
+    codes = np.asarray(codes, dtype=np.uint64)
+    out = np.empty((codes.size, k), dtype=np.uint8)
+    for j in range(k):
+        out[:, j] = _BASES[((codes >> np.uint64(2 * (k - 1 - j))) & np.uint64(3)).astype(np.intp)]
+    return out
+
+
+def count_canonical_kmers(seqs, seq_off, k, min_multiplicity=1, context=None):
+    """(codes ascending, counts) of the canonical k-mers occurring at least min_multiplicity times."""
+    ctx = context or _lib.default_context()
+    return ctx.kmer_count(seqs, seq_off, int(k), int(min_multiplicity))
+
+
+def sample_kmers(n, sample_fraction, seed):
+    """Bernoulli sample of n library candidates: keep where rand() > 1 - p (count_kmers.py:103-117)."""
+    rng = np.random.Generator(np.random.PCG64(int(seed)))
+    return np.flatnonzero(rng.random(int(n)) > 1.0 - float(sample_fraction))
+
+
+def write_kmer_library(path, codes, counts, k):
+    """jellyfish-dump style FASTA: '>count' then the k-mer (count_kmers.py:119-121; read back by
+    precompute.py:44-55)."""
+    kmers = codes_to_kmers(codes, k)
+    with open(path, "wb", buffering=1 << 24) as f:
+        for c, row in zip(np.asarray(counts).tolist(), kmers):
+            f.write(b">%d\n" % c)
+            f.write(row.tobytes())
+            f.write(b"\n")
+
+
+def run_kmer_searcher(input_path, k, sample_fraction, min_multiplicity=2, context=None):
+    """Same signature and return value as the reference (count_kmers.py:52-148):
+    (path of output.bin, number of features = 2 x |forward library|, number of reads).  Writes
+    temp/fwd_kmer_library.fasta, temp/rev_kmer_library.fasta and temp/kmer_searcher/{output.bin,
+    kmer_frequency.bin} like the reference does."""
+    tmp = global_variables.temp_dir
+    if not tmp:
+        raise RuntimeError("global_variables.temp_dir is not set")
+    if input_path.endswith(".gz"):
+        import gzip
+        from shutil import copyfileobj
+        plain = join(tmp, os.path.basename(input_path[:-3]))
+        with gzip.open(input_path, "rb") as src, open(plain, "wb") as dst:
+            copyfileobj(src, dst, 1 << 24)
+        input_path = plain
+    if not input_path.endswith((".fasta", ".fa", ".fastq", ".fq")):
+        raise ValueError("Unsupported file format. Please provide a FASTA or FASTQ file.")  # count_kmers.py:72-75
+    ids, seqs, off = read_sequences(input_path)
+    codes, counts = count_canonical_kmers(seqs, off, k, min_multiplicity, context=context)
+    keep = sample_kmers(codes.size, sample_fraction, global_variables.seed)
+    fwd = join(tmp, "fwd_kmer_library.fasta")
+    write_kmer_library(fwd, codes[keep], counts[keep], k)
+    kmer_count = int(keep.size)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rev = join(tmp, "rev_kmer_library.fasta")
+    with open(fwd, "rb") as f, open(rev, "wb") as g:
+        for line in f:
+            g.write(line if line.startswith(b">") else line.rstrip(b"\n").translate(comp)[::-1] + b"\n")
+    out_dir = join(tmp, "kmer_searcher")
+    ids2, _, _, _ = kmer_searcher([fwd, rev], input_path, out_dir, k, context=context)
+    return join(out_dir, "output.bin"), kmer_count * 2, len(ids2)

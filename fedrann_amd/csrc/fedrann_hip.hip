@@ -12,6 +12,7 @@
 #include <type_traits>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
 
 #include <algorithm>
 #include <cstdarg>
@@ -1790,8 +1791,8 @@ struct fdr_ctx {
     DevBuf a_indptr, a_indices, E, Ehat, zero, idx, dist, ws;
     // k-mer search (kmer_search.inc)
     DevBuf ks_seq, ks_off, ks_codes, ks_keys, ks_vals, ks_bloom, ks_counter, ks_pairs, ks_pairs2, ks_flag, ks_pos,
-        ks_idx, ks_rows, ks_indptr, ks_tmp;
-    long long ks_nnz = 0;
+        ks_idx, ks_rows, ks_indptr, ks_tmp, kc_counts;
+    long long ks_nnz = 0, kc_n = 0;
     // timing: when enabled, every launch of kernel kind i gets its own hipEvent pair on the launch
     // stream; fdr_timing_read() sums the elapsed times of all launches since the last read
     int knn_mode = FDR_MODE_AUTO;
@@ -1866,7 +1867,7 @@ FDR_EXPORT int fdr_destroy(fdr_ctx *ctx) {
                       &ctx->Ehat, &ctx->zero, &ctx->idx, &ctx->dist, &ctx->ws,
                       &ctx->ks_seq, &ctx->ks_off, &ctx->ks_codes, &ctx->ks_keys, &ctx->ks_vals, &ctx->ks_bloom,
                       &ctx->ks_counter, &ctx->ks_pairs, &ctx->ks_pairs2, &ctx->ks_flag, &ctx->ks_pos,
-                      &ctx->ks_idx, &ctx->ks_rows, &ctx->ks_indptr, &ctx->ks_tmp};
+                      &ctx->ks_idx, &ctx->ks_rows, &ctx->ks_indptr, &ctx->ks_tmp, &ctx->kc_counts};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < FDR_NUM_KERNELS; ++i)
         for (hipEvent_t e : ctx->ev_pool[i]) (void)hipEventDestroy(e);

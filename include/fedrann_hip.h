@@ -152,6 +152,17 @@ int fdr_kmer_search(fdr_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, i
                     int64_t *nnz_out);
 int fdr_kmer_search_indices(fdr_ctx *ctx, int32_t *indices_out);
 
+/* ---- canonical k-mer counting on the GPU ---------------------------------------------------------
+ * Replaces `jellyfish count -m k -C` + `jellyfish dump -L min_count` (fedrann/count_kmers.py:80-121):
+ * every window of k characters inside one read whose characters are all in ACGTacgt counts once under
+ * the smaller of its 2-bit code and its reverse complement's.  fdr_kmer_count keeps the k-mers with at
+ * least min_count occurrences on the device and returns their number; fdr_kmer_count_fetch copies
+ * them out in ascending code order (jellyfish dumps in its hash order; the order only names the
+ * features): codes_out, counts_out uint64 [n]. */
+int fdr_kmer_count(fdr_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, int64_t n_reads, int32_t k,
+                   int64_t min_count, int64_t *n_out);
+int fdr_kmer_count_fetch(fdr_ctx *ctx, uint64_t *codes_out, uint64_t *counts_out);
+
 /* ---- kmer_searcher output.bin -> doubled binary CSR (host only: no context, no GPU) ---------------
  * Replaces fedrann/feature_extraction.py:108-140 (parse_kmer_searcher_output: header '<4sB3sQ' =
  * "KMER", version 1, record count; per record '<H' id length, id bytes, '<I' index count, that many

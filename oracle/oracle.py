@@ -316,3 +316,32 @@ def kmer_search(seqs, codes, k):
     if nnz < 0 or nnz > cap:
         raise ValueError("orc_kmer_search failed (%d)" % nnz)
     return indptr, indices[:nnz].copy()
+
+
+def kmer_count(seqs, k, min_count=1):
+    """`jellyfish count -C` + `dump -L` restated with numpy (third-party tool, PARITY UNPINNED): every
+    window of k characters inside one read, all in ACGTacgt, counts under the smaller of its 2-bit code
+    and its reverse complement's.  Returns (codes ascending, counts)."""
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+        lut[c | 0x20] = i
+    allc = []
+    for s in seqs:
+        a = lut[np.frombuffer(bytes(s), dtype=np.uint8)]
+        if a.size < k:
+            continue
+        w = np.lib.stride_tricks.sliding_window_view(a, k)
+        ok = (w != 255).all(axis=1)
+        w = w[ok].astype(np.uint64)
+        fw = np.zeros(w.shape[0], dtype=np.uint64)
+        rc = np.zeros(w.shape[0], dtype=np.uint64)
+        for j in range(k):
+            fw = (fw << np.uint64(2)) | w[:, j]
+            rc = (rc << np.uint64(2)) | (np.uint64(3) - w[:, k - 1 - j])
+        allc.append(np.minimum(fw, rc))
+    if not allc:
+        return np.zeros(0, np.uint64), np.zeros(0, np.uint64)
+    codes, counts = np.unique(np.concatenate(allc), return_counts=True)
+    keep = counts >= min_count
+    return codes[keep], counts[keep].astype(np.uint64)

@@ -111,3 +111,45 @@ def test_cli_from_reads_and_kmer_library(tmp_path, oracle):
     names = [i.decode() for i in s["ids"] for _ in (0, 1)]
     assert got == oracle.overlaps_tsv(idx, dist, names, [0, 1] * 700)
     assert os.path.exists(out_dir / "temp" / "kmer_searcher" / "output.bin")
+
+
+def test_cli_from_reads_only(tmp_path, oracle):
+    """-i reads.fasta alone: k-mer counting, sampling, search, loader, embed, k-NN, writer -- the whole
+    reference pipeline on this build.  The oracle side starts from the library the run sampled (the sample
+    itself depends on the RNG, as it does on the awk implementation in the reference) and restates
+    everything after it."""
+    from fedrann_amd.precompute import read_kmer_counts
+    from fedrann_amd.synth import synth_sequences
+    k = 15
+    s = synth_sequences(600, genome_len=100_000, mean_len=2500, k=k, seed=41)
+    reads = [bytes(s["seqs"][s["seq_off"][i]:s["seq_off"][i + 1]]) for i in range(600)]
+    fa = tmp_path / "reads.fa"
+    fa.write_bytes(b"".join(b">%s\n%s\n" % (i, r) for i, r in zip(s["ids"], reads)))
+    out_dir = tmp_path / "out"
+    cli.main(["-i", str(fa), "-k", str(k), "--kmer-sample-fraction", "0.05", "-o", str(out_dir), "-n", "128",
+              "--nndescent-n-neighbors", "20", "--keep-intermediates", "--seed", "77"])
+    got = open(out_dir / "overlaps.tsv", newline="").read()
+    lib_path = out_dir / "temp" / "fwd_kmer_library.fasta"
+    fwd = [l for l in lib_path.read_bytes().split(b"\n") if l and not l.startswith(b">")]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rev = [x.translate(comp)[::-1] for x in fwd]
+    # the library is what jellyfish count -C | dump -L 2 would hold, sub-sampled
+    wc, wn = oracle.kmer_count(reads, k, 2)
+    from fedrann_amd.count_kmers import codes_to_kmers
+    universe = {r.tobytes(): int(c) for r, c in zip(codes_to_kmers(wc, k), wn)}
+    counts = read_kmer_counts(str(lib_path))
+    assert 0 < len(fwd) < len(universe) and all(universe[x] == c for x, c in zip(fwd, counts.tolist()))
+    L = len(fwd)
+    codes = oracle.kmer_library(b"\n".join(fwd + rev), k)
+    ip, ix = oracle.kmer_search(reads, codes, k)
+    rows = []
+    for r in range(600):
+        idx = ix[ip[r]:ip[r + 1]].astype(np.int64)
+        rows.append(idx.tolist())
+        rows.append(np.where(idx < L, idx + L, idx - L).tolist())
+    P = oracle.precompute_matrix(counts, 128)
+    indptr, indices = oracle.rows_to_csr(rows)
+    E = oracle.embed(indptr, indices, P, 2 * L, 128)
+    idx, dist = oracle.knn(E, 20)
+    names = [i.decode() for i in s["ids"] for _ in (0, 1)]
+    assert got == oracle.overlaps_tsv(idx, dist, names, [0, 1] * 600)

@@ -98,3 +98,51 @@ def test_kmer_searcher_drop_in_writes_reference_files(ctx, oracle, tmp_path):
     assert np.array_equal(ix2[ip2[0]:ip2[1]], ix[ip[0]:ip[1]])
     freq = np.fromfile(str(tmp_path / "out" / "kmer_frequency.bin"), dtype="<u8").reshape(-1, 2)
     assert int(freq[:, 1].sum()) == ix.size
+
+
+@pytest.mark.parametrize("k,min_count", [(15, 2), (5, 1), (31, 1), (21, 3)])
+def test_kmer_count_matches_numpy_restatement(ctx, oracle, k, min_count):
+    """fdr_kmer_count (jellyfish count -C | dump -L): canonical codes and counts, windows with an invalid
+    character or crossing a read boundary skipped, reads shorter than k contribute nothing."""
+    s = synth_sequences(1500, genome_len=60_000, mean_len=1500, k=k, sample=0.01, n_rate=2e-3, seed=300 + k)
+    seqs, off = s["seqs"].copy(), s["seq_off"]
+    seqs[::501] |= 0x20
+    codes, counts = ctx.kmer_count(seqs, off, k, min_count)
+    wc, wn = oracle.kmer_count(_reads(seqs, off), k, min_count)
+    assert np.array_equal(codes, wc) and np.array_equal(counts, wn)
+    assert codes.size > 0 and int(counts.min()) >= min_count
+    # short and empty reads, nothing valid at all
+    reads = [b"ACGT", b"", b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN", b"AC"]
+    o = np.zeros(5, dtype=np.int64)
+    o[1:] = np.cumsum([len(r) for r in reads])
+    c2, n2 = ctx.kmer_count(np.frombuffer(b"".join(reads), dtype=np.uint8), o, k, 1)
+    w2, m2 = oracle.kmer_count(reads, k, 1)
+    assert np.array_equal(c2, w2) and np.array_equal(n2, m2)
+
+
+def test_run_kmer_searcher_from_reads_only(ctx, oracle, tmp_path):
+    """count_kmers.run_kmer_searcher: FASTA in; library files, output.bin out; same return tuple as the
+    reference.  The library equals the thresholded canonical counts filtered by the documented sampler."""
+    from fedrann_amd import count_kmers as ck
+    from fedrann_amd import global_variables as gv
+    from fedrann_amd.precompute import read_kmer_counts
+    s = synth_sequences(400, genome_len=50_000, mean_len=2000, k=15, seed=55)
+    reads = _reads(s["seqs"], s["seq_off"])
+    fa = tmp_path / "reads.fasta"
+    fa.write_bytes(b"".join(b">%s\n%s\n" % (i, r) for i, r in zip(s["ids"], reads)))
+    gv.temp_dir, gv.seed = str(tmp_path / "temp"), 1234
+    (tmp_path / "temp").mkdir()
+    out_bin, n_features, read_count = ck.run_kmer_searcher(str(fa), 15, 0.05, 2, context=ctx)
+    assert read_count == 400 and n_features % 2 == 0
+    wc, wn = oracle.kmer_count(reads, 15, 2)
+    keep = ck.sample_kmers(wc.size, 0.05, 1234)
+    assert n_features == 2 * keep.size
+    assert np.array_equal(read_kmer_counts(str(tmp_path / "temp" / "fwd_kmer_library.fasta")), wn[keep].astype(np.int64))
+    fwd_text = b"\n".join(r.tobytes() for r in ck.codes_to_kmers(wc[keep], 15)) + b"\n"
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rev_text = b"\n".join(r.tobytes().translate(comp)[::-1] for r in ck.codes_to_kmers(wc[keep], 15)) + b"\n"
+    lib = oracle.kmer_library(fwd_text + rev_text, 15)
+    wp, wx = oracle.kmer_search(reads, lib, 15)
+    ip2, ix2, names, strands = fx.build_feature_csr(out_bin, n_features)
+    for r in (0, 7, 399):
+        assert np.array_equal(ix2[ip2[2 * r]:ip2[2 * r + 1]], wx[wp[r]:wp[r + 1]])
