@@ -2053,21 +2053,10 @@ static const KnnShape kShapes[] = {
     {128, 1, 4, 4, 4},  // d <= 128: <= 128 VGPRs, 4 WG/CU
     {256, 1, 4, 3, 4},  // d <= 256: <= 168 VGPRs, one tile per stage
     {512, 1, 4, 2, 4},  // d <= 512: 128 VGPRs of queries, half a tile per stage
-    {128, 1, 8, 4, 4},  // 8 waves: 256 queries/WG (half the staging traffic per query)
-    {256, 1, 8, 3, 4},
-    {512, 1, 8, 2, 4},
-    {128, 2, 8, 2, 4},  // 8 waves x 2 query sets: 512 queries/WG
 };
 #define FDR_SHAPE_PREFILTER 5  // + 0 / 1 / 2 for d <= 128 / 256 / 512
 static int range_shape(int dp) { return FDR_SHAPE_PREFILTER + (dp == 128 ? 0 : dp == 256 ? 1 : 2); }
-static int prefilter_shape(int dp) {
-    const int base = FDR_SHAPE_PREFILTER + (dp == 128 ? 0 : dp == 256 ? 1 : 2);
-    if (const char *e = getenv("FDR_KNN_PSHAPE")) {  // development knob: 8 = 8-wave form, 16 = 8 waves x 2 sets
-        if (atoi(e) == 8) return base + 3;
-        if (atoi(e) == 16 && dp == 128) return FDR_SHAPE_PREFILTER + 6;
-    }
-    return base;
-}
+static int prefilter_shape(int dp) { return range_shape(dp); }
 
 static size_t knn_lds_bytes_q(const KnnShape &sh, int k, int qcap) {
     const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
@@ -2434,18 +2423,14 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
         if (kp <= 32) FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 16);                                     \
         else FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 32);                                              \
     } while (0)
-    if (dp == 128 && sh.nw == 8 && sh.nq == 2) FDR_LAUNCH_PRE(128, 2, 8, 2, 2);
-    else if (dp == 128 && sh.nw == 8) FDR_LAUNCH_PRE(128, 1, 8, 4, 2);
-    else if (dp == 128 && kp <= 32 && !(getenv("FDR_KNN_PAIR") && atoi(getenv("FDR_KNN_PAIR")) == 0)) {
+    if (dp == 128 && kp <= 32 && !(getenv("FDR_KNN_PAIR") && atoi(getenv("FDR_KNN_PAIR")) == 0)) {
         // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
         // <= 128 VGPRs.  FDR_KNN_PAIR=0: development knob, one chain)
         hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)p.nqb, (unsigned)p.nseg),
                            dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad,
                            d_partial, d_shared, ib, pdbg);
     } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
-    else if (dp == 256 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 3, 2);
     else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
-    else if (sh.nw == 8) FDR_LAUNCH_PRE(512, 1, 8, 2, 2);
     else FDR_LAUNCH_PRE(512, 1, 4, 2, 2);
 #undef FDR_LAUNCH_PRE2
 #undef FDR_LAUNCH_PRE
