@@ -1070,6 +1070,28 @@ __device__ __forceinline__ u64 wave_sort64(u64 key, const int lane) {
     return key;
 }
 
+// Ascending bitonic sort of 128 keys, two per lane: a = element `lane`, b = element `lane + 64`.
+__device__ __forceinline__ void wave_sort128(u64 &a, u64 &b, const int lane) {
+#pragma unroll
+    for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 64) {  // (k == 128: ascending) partner = the lane's other element
+                const u64 lo = a < b ? a : b, hi = a < b ? b : a;
+                a = lo;
+                b = hi;
+            } else {
+                const u64 oa = __shfl_xor(a, j), ob = __shfl_xor(b, j);
+                const bool up_a = k >= 64 || (lane & k) == 0;               // direction of element lane
+                const bool up_b = k == 128 || (k < 64 && (lane & k) == 0);  // ... of element lane + 64
+                const bool lower = (lane & j) == 0;
+                a = ((lower == up_a) == (oa < a)) ? oa : a;
+                b = ((lower == up_b) == (ob < b)) ? ob : b;
+            }
+        }
+    }
+}
+
 // P1's merge: the KP smallest keys of a query's nseg segment lists, sorted.  One wave per query.
 // A segment list arrives as two ascending halves ([0, ceil(KP/2)) and the rest; KEY_INF = empty slot),
 // so a full list's maximum is the larger of the two last entries, and the smallest such maximum over
@@ -1082,7 +1104,7 @@ __global__ __launch_bounds__(256) void knn_merge_keys_kernel(const u64 *__restri
                                                              int nq, int nq_pad, int KP,
                                                              u64 *__restrict__ cand) {
     __shared__ u64 stage[4][MERGE_CAP];
-    static_assert(MERGE_CAP >= 128, "a wave's stage row doubles as its survivor buffer (128 keys)");
+    static_assert(MERGE_CAP >= 256, "a wave's stage row doubles as its survivor buffer (256 keys)");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u64 *sv = stage[wave];
     const int q = blockIdx.x * 4 + wave;
@@ -1118,7 +1140,7 @@ __global__ __launch_bounds__(256) void knn_merge_keys_kernel(const u64 *__restri
                     const bool keep = kv <= bound;  // (bound < KEY_INF)
                     const u64 mask = __ballot(keep);
                     const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (keep && pos < 128) sv[pos] = kv;
+                    if (keep && pos < 256) sv[pos] = kv;
                     total += __popcll(mask);
                 }
                 sg0 += 8;
@@ -1126,26 +1148,37 @@ __global__ __launch_bounds__(256) void knn_merge_keys_kernel(const u64 *__restri
                 load_batch(sg0);
             }
         }
-        if (bound != KEY_INF && total <= 128) {  // (total >= KP: the bounding list alone has KP such keys)
-            u64 kv = wave_sort64(lane < total ? sv[lane] : KEY_INF, lane);
-            bool done = total <= 64;
+        if (bound != KEY_INF && total <= 256) {  // (total >= KP: the bounding list alone has KP such keys)
+            if (total <= 64) {
+                const u64 kv = wave_sort64(lane < total ? sv[lane] : KEY_INF, lane);
+                if (lane < KP) cand[(size_t)q * KP + lane] = kv;
+                return;
+            }
+            u64 ka = sv[lane];  // (total > 64)
+            u64 kb = 64 + lane < total ? sv[64 + lane] : KEY_INF;
+            wave_sort128(ka, kb, lane);
+            bool done = total <= 128;
             if (!done) {
-                const u64 b2 = __shfl(kv, KP - 1);  // KP-th of the first 64: nothing above it is needed
-                const u64 extra = 64 + lane < total ? sv[64 + lane] : KEY_INF;
-                const bool keep = extra <= b2;
-                const u64 mask = __ballot(keep);
-                const int nx = __popcll(mask);
-                if (KP + nx <= 64) {
-                    const int pos = KP + __popcll(mask & ((1ull << lane) - 1ull));
-                    // second sort: lanes [0, KP) keep their key, the extras are appended through LDS
-                    if (keep) sv[pos] = extra;
-                    const u64 merged = lane < KP ? kv : (lane < KP + nx ? sv[lane] : KEY_INF);
-                    kv = wave_sort64(merged, lane);
+                // the KP-th of the first 128 bounds what is still needed from the other (at most 128) survivors
+                const u64 b2 = __shfl(ka, KP - 1);
+                const u64 e0 = 128 + lane < total ? sv[128 + lane] : KEY_INF;
+                const u64 e1 = 192 + lane < total ? sv[192 + lane] : KEY_INF;
+                const bool k0 = e0 <= b2, k1 = e1 <= b2;
+                const u64 m0 = __ballot(k0), m1 = __ballot(k1);
+                const int n0 = __popcll(m0), nx = n0 + __popcll(m1);
+                if (KP + nx <= 128) {
+                    const u64 below = (1ull << lane) - 1ull;
+                    if (lane < KP) sv[lane] = ka;
+                    if (k0) sv[KP + __popcll(m0 & below)] = e0;
+                    if (k1) sv[KP + n0 + __popcll(m1 & below)] = e1;
+                    ka = lane < KP + nx ? sv[lane] : KEY_INF;
+                    kb = 64 + lane < KP + nx ? sv[64 + lane] : KEY_INF;
+                    wave_sort128(ka, kb, lane);
                     done = true;
                 }
             }
             if (done) {
-                if (lane < KP) cand[(size_t)q * KP + lane] = kv;
+                if (lane < KP) cand[(size_t)q * KP + lane] = ka;  // (KP <= 64: the first element of each lane)
                 return;
             }
         }
