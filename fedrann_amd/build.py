@@ -20,8 +20,9 @@ def hipcc_path():
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    deps = [SRC, os.path.join(HERE, "csrc", "kmer_output_loader.inc"), os.path.join(HERE, "csrc", "kmer_search.inc"),
-            os.path.join(HERE, "..", "include", "fedrann_hip.h")]
+    csrc = os.path.join(HERE, "csrc")
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc"))]
+    deps.append(os.path.join(HERE, "..", "include", "fedrann_hip.h"))
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 
