@@ -214,6 +214,8 @@ def main():
     found = (idx == rows[:, None]).any(1) | (dst[:, -1] <= 1e-6)
     ok = bool(np.all(found[nz])) and bool(np.all(np.diff(dst, axis=1) >= 0))
     zero_frac = float(1.0 - nz.mean()) if nz.size else 0.0
+    # rows whose list ends inside a run of equal distances (the k-th neighbour is decided by the index)
+    tie_frac = float((dst[:, -1] == dst[:, -2]).mean()) if dst.shape[0] and dst.shape[1] > 1 else 0.0
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -258,7 +260,8 @@ def main():
                                                                   d, k, world),
                        "reads": R, "rows": n, "dim": d, "knn": k, "n_features": int(s["n_features"]),
                        "nnz": int(s["indptr"][-1]), "parallelism": "rows/%d + all-gather" % world,
-                       "zero_row_fraction_sample": zero_frac, "self_check": ok},
+                       "zero_row_fraction_sample": zero_frac, "boundary_tie_fraction_sample": tie_frac,
+                       "self_check": ok},
             "roofline": dict(roof, traffic=traffic,
                              traffic_source="profiles/r1_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                             "bytes per launch)" if traffic else None),
