@@ -996,7 +996,7 @@ struct DedupLayout {
 
 static bool knn_dedup_wanted(int64_t nq, int64_t nt) {
     if (const char *e = getenv("FDR_KNN_DEDUP")) return atoi(e) != 0;  // development knob
-    return nt >= 16384 && nq >= 1024;
+    return nt >= 8192 && nq >= 1024;  // (from the size at which the prefilter mode engages)
 }
 
 static DedupLayout dedup_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {

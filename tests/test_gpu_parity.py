@@ -17,7 +17,7 @@ def knn_mode(request, monkeypatch):
     """Every test runs under both k-NN modes.  "prefilter" = fp16 MFMA candidate pass + certificate +
     exact fp32 re-rank (exact kernel for uncertified queries); its results must be the same bits.
     "+classes" forces the duplicate-row class layer (search unique rows, expand) at every size -- by
-    default it only engages from 16384 target rows, which the large tests below cover."""
+    default it only engages from 8192 target rows, which the large tests below cover."""
     mode, _, classes = request.param.partition("+")
     monkeypatch.setenv("FDR_KNN_MODE", mode)
     if classes:
