@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """libfedrann_hip.so is a build product (git-ignored): compile it if this checkout has none or an
+    outdated one (hipcc cross-compiles gfx950 without a GPU; ~2 minutes the first time)."""
+    from fedrann_amd import build
+    build.build_library()
+
+
 def golden(name):
     return os.path.join(GOLDEN, name)
 
