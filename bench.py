@@ -6,15 +6,24 @@
 
 A step = one pass of the hot path over the whole synthetic read set: every rank embeds and
 normalises its row block, the normalised embeddings are all-gathered (N > 1), and every rank
-searches its rows against all targets.  Default workload = BASELINE.json configs[1]: 100k synthetic
-ONT reads, 128-dim projection, k-NN = 20.  Inputs (the read x k-mer CSR and the projection
-tables) are resident in HBM before the timed region; results stay in HBM.  The total work is the
-same for every N (strong scaling): value = R * k * steps / time.
+searches its rows against all targets.  Default workload = BASELINE.json configs[2], the largest
+single-GPU configuration: 1 M synthetic ONT reads, 128-dim projection, k-NN = 20 (configs[1] =
+--reads 100000; configs[3] = --reads 10000000 on 8 GPUs; configs[4] = --reads 10000000 --doubling
+--dim 256 --knn 50).  The total work is the same for every N (strong scaling).
+
+`value` = R * k * steps / time with the inputs (the rank's CSR rows, the projection tables) resident
+in HBM when the timed region starts and the results left in HBM.  `host_to_host` (N = 1) is the span
+SURVEY.md section 8(d) words: CSR in (pinned) host memory -> (indices, distances) in host memory through
+fdr_embed_knn, i.e. with the PCIe copies inside the timed region -- once with the CSR as the loader
+delivers it and once with the dead features dropped on the host first (fdr_csr_compact; not timed,
+it belongs to the loader).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the timed mode (the fp16 MFMA
 prefilter pass by default, the fp32 MFMA tile kernel in exact mode), priced on the unique rows it
-actually searched; `cpu_baseline` times this repo's CPU oracle (a port of the path, not the reference's pynndescent,
-which is not installed) on a bounded sample of the same workload.
+actually searched; `cpu_baseline` times this repo's CPU oracle (a port of the path, not the reference's
+pynndescent, which is not installed) on a bounded sample of the same workload; `recall` compares the
+timed run's rows with the oracle's (tie-aware recall@k) and, when it imports, with pynndescent called
+as the reference calls it.
 """
 import argparse
 import json
@@ -36,7 +45,8 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--reads", type=int, default=100_000, help="rows of the feature matrix")
+    p.add_argument("--reads", type=int, default=1_000_000,
+                   help="reads (= rows of the feature matrix, x2 with --doubling)")
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--knn", type=int, default=20)
     p.add_argument("--seed", type=int, default=602)
@@ -48,6 +58,9 @@ def parse_args():
                         "default: fp16 prefilter + certificate + exact re-rank when it applies")
     p.add_argument("--no-compare", action="store_true",
                    help="skip the extra (separately timed) pass in the other k-NN mode")
+    p.add_argument("--compare-steps", type=int, default=2, help="steps of the other-mode pass")
+    p.add_argument("--no-host-span", action="store_true", help="skip the host-to-host (PCIe-inclusive) passes")
+    p.add_argument("--host-steps", type=int, default=3, help="steps of each host-to-host pass")
     return p.parse_args()
 
 
@@ -62,6 +75,51 @@ def cpu_budget():
     except Exception:
         pass
     return n
+
+
+def tie_aware_recall(got_idx, want_dist, Eh, zero, k):
+    """recall@k of `got_idx` against the exact k-NN whose ascending distances are `want_dist`: a returned
+    neighbour counts when its canonical distance to the query is <= the exact k-th distance (so any member
+    of a tie across the rank-k boundary is as good as another).  Query i is row i of Eh."""
+    import numpy as np
+    from oracle import oracle as O
+    m = got_idx.shape[0]
+    if m == 0:
+        return None
+    step = max(1, m // 2048)  # pair distances one at a time: a sample of the sample
+    rows = np.arange(0, m, step)
+    hits = 0
+    for q in rows:
+        kth = want_dist[q, k - 1]
+        for t in got_idx[q]:
+            hits += O.pair_dist_normalized(Eh[q], zero[q], Eh[t], zero[t]) <= kth
+    return hits / float(rows.size * k)
+
+
+def pynndescent_recall(ctx, E, k, cores, seed, rows=20000):
+    """The reference's own k-NN call (nearest_neighbors.py:39-55 with the arguments of __main__.py:184-197)
+    on the first `rows` embeddings, if the third-party package imports on this box.  Its graph and the
+    GPU's result for the same sub-sample are both scored against the exact oracle (tie-aware recall@k).
+    Returns (dict | None, reason)."""
+    import numpy as np
+    try:
+        import pynndescent
+    except Exception as e:  # not installed in this image (no network): reported, never faked
+        return None, "import pynndescent failed (%s: %s)" % (type(e).__name__, e)
+    from oracle import oracle as O
+    sub = np.ascontiguousarray(E[:rows])
+    Eh, _, zero = O.normalize(sub)
+    _, want_dist = O.knn_normalized(Eh, zero, Eh, zero, k)
+    t0 = time.perf_counter()
+    index = pynndescent.NNDescent(sub, metric="cosine", n_neighbors=k, n_trees=300, leaf_size=200, n_iters=None,
+                                  diversify_prob=1.0, pruning_degree_multiplier=1.5, low_memory=True,
+                                  n_jobs=cores, random_state=seed, verbose=False)
+    p_idx, _ = index.neighbor_graph
+    dt = time.perf_counter() - t0
+    g_idx, _ = ctx.knn(sub, k)
+    return {"rows": int(sub.shape[0]), "pynndescent_vs_exact": tie_aware_recall(np.maximum(p_idx, 0), want_dist, Eh, zero, k),
+            "gpu_vs_exact": tie_aware_recall(g_idx, want_dist, Eh, zero, k),
+            "pynndescent_read_pairs_per_s": sub.shape[0] * k / dt, "pynndescent_seconds": dt, "cores": cores}, None
 
 
 def cpu_baseline(s, P, d, k, target_seconds, gpu_result=None):
@@ -96,7 +154,9 @@ def cpu_baseline(s, P, d, k, target_seconds, gpu_result=None):
         m = min(nq, gpu_result[0].shape[0])
         same = bool(np.array_equal(gpu_result[0][:m], o_idx[:m])) and bool(
             np.array_equal(gpu_result[1][:m].view(np.uint32), o_dist[:m].view(np.uint32)))
-        parity = {"rows": int(m), "identical_indices_and_distance_bits": same}
+        parity = {"rows": int(m), "identical_indices_and_distance_bits": same,
+                  "recall_at_k_tie_aware": tie_aware_recall(gpu_result[0][:m], o_dist[:m], Eh, zero, k),
+                  "max_abs_distance_error": float(np.abs(gpu_result[1][:m] - o_dist[:m]).max()) if m else 0.0}
     return {
         "parity_sample": parity,
         "value": n * k / est_total, "unit": "read-pairs/s", "cores": cores, "kind": "port",
@@ -142,8 +202,19 @@ def main():
     from fedrann_amd.synth import synth
 
     R, d, k = args.reads, args.dim, args.knn
-    s = synth(R, seed=args.seed, doubling=args.doubling)
-    n = len(s["indptr"]) - 1
+    per = 2 if args.doubling else 1
+    n = R * per
+    # every rank generates only ITS rows (chunk-seeded generator: the same reads whichever rank makes them)
+    from fedrann_amd.distributed import shard_rows
+    _, blocks = shard_rows(n, world)
+    lo, hi = blocks[rank]
+    chunk = 100_000
+    r_lo, r_hi = lo // per, -(-hi // per)
+    g_lo = r_lo // chunk * chunk
+    s = synth(R, seed=args.seed, doubling=args.doubling, chunk=chunk, reads=(g_lo, r_hi))
+    skip = lo - g_lo * per
+    ip = np.ascontiguousarray(s["indptr"][skip:skip + (hi - lo) + 1] - s["indptr"][skip])
+    ix = np.ascontiguousarray(s["indices"][s["indptr"][skip]:s["indptr"][skip + (hi - lo)]])
     P = build_precompute_matrix(s["counts"], d)
 
     ctx = _lib.Context(local_rank)
@@ -151,10 +222,15 @@ def main():
     ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], d)
     engine = HipEngine(ctx, device)
     pipe = ShardedPipeline(engine, n, d, k, rank=rank, world_size=world, device=device)
-    ip, ix = local_csr(s["indptr"], s["indices"], pipe.lo, pipe.hi)
+    assert (pipe.lo, pipe.hi) == (lo, hi)
     d_ip = torch.from_numpy(ip).to(device)
     d_ix = torch.from_numpy(ix).to(device)
     nloc = pipe.hi - pipe.lo
+    nnz_total = int(ix.size)
+    if world > 1:
+        t = torch.tensor([nnz_total], dtype=torch.int64, device=device)
+        dist.all_reduce(t)
+        nnz_total = int(t.item())
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -196,13 +272,38 @@ def main():
     if not args.no_compare and (used_prefilter or args.mode != "exact"):
         other_mode = "exact" if used_prefilter else "prefilter"
         ctx.set_knn_mode(other_mode)
-        o_elapsed, o_ms, o_cnt, o_out = timed_run(args.steps, min(args.warmup, 1))
+        o_steps = max(1, min(args.steps, args.compare_steps))
+        o_elapsed, o_ms, o_cnt, o_out = timed_run(o_steps, min(args.warmup, 1))
         same = bool(torch.equal(out[0], o_out[0])) and bool(torch.equal(out[1], o_out[1]))
         if o_cnt["knn_prefilter"] > 0 or other_mode == "exact":
-            other = {"mode": other_mode, "value": n * k * args.steps / o_elapsed, "unit": "read-pairs/s",
-                     "ms_per_step": o_elapsed / args.steps * 1e3, "kernels_ms": o_ms,
+            other = {"mode": other_mode, "value": n * k * o_steps / o_elapsed, "unit": "read-pairs/s",
+                     "steps": o_steps, "ms_per_step": o_elapsed / o_steps * 1e3, "kernels_ms": o_ms,
                      "identical_to_timed_run": same}
         ctx.set_knn_mode(args.mode)
+
+    # SURVEY.md 8(d)'s span, N = 1: CSR in pinned host memory -> (idx, dist) in pinned host memory through the
+    # fused host-pointer call (H2D, embed, normalise, k-NN, D2H).  Never `value` (the contract times the
+    # device-resident path); same results, checked.
+    host_span = None
+    if world == 1 and not args.no_host_span:
+        h_idx = np.empty((n, k), dtype=np.int32)
+        h_dst = np.empty((n, k), dtype=np.float32)
+        cip, cix = ctx.csr_compact(ip, ix)  # what a loader that knows P hands over (not timed: loader work)
+        host_span = {"steps": args.host_steps, "unit": "read-pairs/s"}
+        for label, (a_ip, a_ix) in (("full_csr", (ip, ix)), ("compacted_csr", (cip, cix))):
+            ctx.host_register(a_ip, a_ix, h_idx, h_dst)
+            ctx.embed_knn(a_ip, a_ix, k, out=(h_idx, h_dst))  # warm-up: scratch buffers sized, tables hot
+            t0 = time.perf_counter()
+            for _ in range(args.host_steps):
+                ctx.embed_knn(a_ip, a_ix, k, out=(h_idx, h_dst))  # (synchronises before it returns)
+            dt = time.perf_counter() - t0
+            ctx.host_unregister(a_ip, a_ix, h_idx, h_dst)
+            same = bool(np.array_equal(h_idx, out[0].cpu().numpy())) and bool(
+                np.array_equal(h_dst.view(np.uint32), out[1].cpu().numpy().view(np.uint32)))
+            host_span[label] = {"value": n * k * args.host_steps / dt, "ms_per_step": dt / args.host_steps * 1e3,
+                                "h2d_bytes": int(a_ip.nbytes + a_ix.nbytes), "d2h_bytes": int(h_idx.nbytes + h_dst.nbytes),
+                                "identical_to_timed_run": same}
+        del h_idx, h_dst, cip, cix
 
     # sanity on the last step's result (not timed): self is its own nearest neighbour
     idx = out[0][: min(nloc, 4096)].cpu().numpy()
@@ -238,14 +339,16 @@ def main():
         nnz_loc = int(ix.size)
         embed_bytes = 4.0 * nnz_loc + 8.0 * nloc + 4.0 * nloc * d
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as the
-        # gfx950 guide prescribes + WRITE_SIZE); only valid for the workload it was collected on
-        traffic = None
+        # gfx950 guide prescribes + WRITE_SIZE); only valid for the workload the profile was collected on
+        traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r2_summary.json")) as f:
                 prof = json.load(f)
-            if (R, d, k, world, args.doubling) == (100_000, 128, 20, 1, False):
+            if prof.get("bench_args") == {"reads": R, "dim": d, "knn": k, "gpus": world, "doubling": args.doubling}:
                 kname = "knn_prefilter_kernel" if used_prefilter else "knn_tile_kernel"
                 traffic = prof["pmc_per_launch_avg"][kname]["hbm_bytes_per_launch"]
+                traffic_src = ("profiles/r2_summary.json (rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + "
+                               "WRITE_SIZE, bytes per launch, same workload)")
         except Exception:
             traffic = None
         result = {
@@ -258,13 +361,14 @@ def main():
             "config": {"workload": "%d synthetic ONT reads (%d rows%s), %d-dim projection, k-NN=%d, "
                                    "row-sharded over %d GPU(s)" % (R, n, ", fwd/rev doubled" if args.doubling else "",
                                                                   d, k, world),
-                       "reads": R, "rows": n, "dim": d, "knn": k, "n_features": int(s["n_features"]),
-                       "nnz": int(s["indptr"][-1]), "parallelism": "rows/%d + all-gather" % world,
+                       "reads": R, "rows": n, "dim": d, "knn": k, "doubling": bool(args.doubling),
+                       "n_features": int(s["n_features"]),
+                       "nnz": nnz_total, "parallelism": "rows/%d + all-gather" % world,
                        "zero_row_fraction_sample": zero_frac, "boundary_tie_fraction_sample": tie_frac,
                        "self_check": ok},
-            "roofline": dict(roof, traffic=traffic,
-                             traffic_source="profiles/r1_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                            "bytes per launch)" if traffic else None),
+            "roofline": dict(roof, traffic=traffic, traffic_source=traffic_src),
+            "value_span": "inputs resident in HBM -> results in HBM (bench contract); host_to_host = SURVEY 8(d) span",
+            "host_to_host": host_span,
             "knn_mode": "prefilter" if used_prefilter else "exact",
             "uncertified_queries_last_step": uncertified if used_prefilter else None,
             "unique_rows_searched": {"targets": uniq_t, "queries": uniq_q, "of_targets": n, "of_queries": nloc},
@@ -278,9 +382,17 @@ def main():
             result["other_mode"] = other
         if world == 1 and args.cpu_baseline_seconds > 0:
             m = min(nloc, 1 << 17)
-            result["cpu_baseline"] = cpu_baseline(s, P, d, k, args.cpu_baseline_seconds,
-                                                  gpu_result=(out[0][:m].cpu().numpy(), out[1][:m].cpu().numpy()))
+            base = cpu_baseline(s, P, d, k, args.cpu_baseline_seconds,
+                                gpu_result=(out[0][:m].cpu().numpy(), out[1][:m].cpu().numpy()))
+            par = base.get("parity_sample") or {}
+            pyn, why = pynndescent_recall(ctx, out[2].cpu().numpy(), k, base["cores"], args.seed)
+            result["recall"] = {"recall_vs_oracle": par.get("recall_at_k_tie_aware"),
+                                "oracle_rows_compared": par.get("rows"),
+                                "ranks_and_distance_bits_identical": par.get("identical_indices_and_distance_bits"),
+                                "recall_vs_pynndescent": pyn, "recall_vs_pynndescent_reason": why}
+            result["cpu_baseline"] = base
         else:
+            result["recall"] = None
             result["cpu_baseline"] = None
         print(json.dumps(result))
     if world > 1:

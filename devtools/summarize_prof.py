@@ -59,7 +59,18 @@ for r in csv.DictReader(open(os.path.join(dst, "%s_kernel_stats.csv" % tag))):
     k = short(r["Name"])
     if k:
         stats[k] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])}
-json.dump({"tag": tag, "workload": "bench.py default (100k reads, d=128, k=20, 1 GPU)",
+bench_args, workload = None, None
+try:  # the bench line of the kernel-trace run names the workload the counters belong to
+    line = [l for l in open(os.path.join(src, "prof_%s.bench.json" % tag)).read().splitlines() if l.startswith("{")][-1]
+    cfg = json.loads(line)
+    c = cfg["config"]
+    bench_args = {"reads": c["reads"], "dim": c["dim"], "knn": c["knn"], "gpus": cfg["n_gpus"],
+                  "doubling": bool(c.get("doubling", c["rows"] != c["reads"]))}
+    workload = c["workload"]
+    shutil.copy(os.path.join(src, "prof_%s.bench.json" % tag), os.path.join(dst, "%s_bench.json" % tag))
+except Exception as e:
+    print("no bench line:", e)
+json.dump({"tag": tag, "workload": workload, "bench_args": bench_args,
            "kernel_stats": stats, "pmc_per_launch_avg": out}, open(os.path.join(dst, "%s_summary.json" % tag), "w"),
           indent=1, sort_keys=True)
 print(json.dumps({"kernel_stats": stats, "pmc": {k: {c: v for c, v in cs.items() if "bytes" in c or "frac" in c}

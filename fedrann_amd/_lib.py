@@ -15,9 +15,9 @@ SYMBOLS = (
     "fdr_create", "fdr_destroy", "fdr_last_error", "fdr_device_info", "fdr_padded_dim",
     "fdr_projection_load", "fdr_embed", "fdr_knn", "fdr_embed_knn", "fdr_embed_dev",
     "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_timing", "fdr_timing_read",
-    "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_last_unique", "fdr_kmer_output_scan",
+    "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_set_dedup_mode", "fdr_last_unique", "fdr_kmer_output_scan",
     "fdr_kmer_output_load", "fdr_kmer_search", "fdr_kmer_search_indices", "fdr_kmer_count",
-    "fdr_kmer_count_fetch",
+    "fdr_kmer_count_fetch", "fdr_csr_compact", "fdr_host_register", "fdr_host_unregister",
 )
 FDR_MAX_K = 64
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
@@ -81,10 +81,14 @@ def load_library():
     L.fdr_knn_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, vp, sz, vp]
     L.fdr_last_uncertified.argtypes = [vp]
     L.fdr_set_knn_mode.argtypes = [vp, ctypes.c_int]
+    L.fdr_set_dedup_mode.argtypes = [vp, ctypes.c_int]
     L.fdr_last_unique.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     p64 = ctypes.POINTER(ctypes.c_int64)
     L.fdr_kmer_output_scan.argtypes = [ctypes.c_char_p, p64, p64, p64]
-    L.fdr_kmer_output_load.argtypes = [ctypes.c_char_p, i64, i32, vp, vp, vp, vp]
+    L.fdr_kmer_output_load.argtypes = [ctypes.c_char_p, i64, i32, i64, i64, i64, vp, vp, vp, vp]
+    L.fdr_csr_compact.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32]
+    L.fdr_host_register.argtypes = [vp, vp, sz]
+    L.fdr_host_unregister.argtypes = [vp, vp]
     L.fdr_kmer_search.argtypes = [vp, vp, vp, i64, vp, i64, i32, vp, p64]
     L.fdr_kmer_search_indices.argtypes = [vp, vp]
     L.fdr_kmer_count.argtypes = [vp, vp, vp, i64, i32, i64, p64]
@@ -124,8 +128,8 @@ def kmer_output_load(path, n_features, n_threads=0):
     indices = np.empty(2 * nnz.value, dtype=np.int32)
     name_off = np.empty(R.value + 1, dtype=np.int64)
     names = np.empty(nb.value, dtype=np.uint8)
-    rc = L.fdr_kmer_output_load(bpath, int(n_features), int(n_threads), indptr.ctypes.data,
-                                indices.ctypes.data, name_off.ctypes.data, names.ctypes.data)
+    rc = L.fdr_kmer_output_load(bpath, int(n_features), int(n_threads), R.value, nnz.value, nb.value,
+                                indptr.ctypes.data, indices.ctypes.data, name_off.ctypes.data, names.ctypes.data)
     if rc != 0:
         raise FedrannHipError("fdr_kmer_output_load failed (%d): %s" % (rc, L.fdr_last_error().decode()))
     return indptr, indices, name_off, names
@@ -187,6 +191,12 @@ class Context:
         code = {"auto": 0, "exact": 1, "prefilter": 2}[mode]
         self._check(self._L.fdr_set_knn_mode(self._h, code), "fdr_set_knn_mode")
 
+    def set_dedup_mode(self, mode):
+        """Duplicate-row classes: "auto" (default), "off", "on" (at every size) or "force" (always expand;
+        tests) -- same results, see include/fedrann_hip.h."""
+        code = {"auto": 0, "off": 1, "on": 2, "force": 3}[mode]
+        self._check(self._L.fdr_set_dedup_mode(self._h, code), "fdr_set_dedup_mode")
+
     def kmer_search(self, seqs, seq_off, lib_codes, k):
         """Per-read ascending unique library indices: (indptr int64 [R+1], indices int32 [nnz])."""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
@@ -247,6 +257,28 @@ class Context:
                                                 _ptr(p_cols), _ptr(p_vals)), "fdr_projection_load")
         self.n_features, self.d = int(n_features), int(d)
 
+    def csr_compact(self, a_indptr, a_indices, n_threads=0):
+        """The CSR without the column ids whose projection row is empty (same E, ~10x fewer ids)."""
+        a_indptr = _as(a_indptr, np.int64, "a_indptr")
+        a_indices = _as(a_indices, np.int32, "a_indices")
+        n = a_indptr.shape[0] - 1
+        out_ip = np.empty(n + 1, dtype=np.int64)
+        out_ix = np.empty(max(int(a_indices.size), 1), dtype=np.int32)
+        self._check(self._L.fdr_csr_compact(self._h, n, _ptr(a_indptr), _ptr(a_indices), _ptr(out_ip),
+                                            _ptr(out_ix), int(out_ix.size), int(n_threads)), "fdr_csr_compact")
+        return out_ip, np.ascontiguousarray(out_ix[:int(out_ip[-1])])
+
+    def host_register(self, *arrays):
+        """Pin numpy arrays the caller keeps passing to embed / knn / embed_knn (PCIe-rate copies)."""
+        for a in arrays:
+            if a is not None and a.nbytes:
+                self._check(self._L.fdr_host_register(self._h, a.ctypes.data, a.nbytes), "fdr_host_register")
+
+    def host_unregister(self, *arrays):
+        for a in arrays:
+            if a is not None and a.nbytes:
+                self._check(self._L.fdr_host_unregister(self._h, a.ctypes.data), "fdr_host_unregister")
+
     def embed(self, a_indptr, a_indices):
         a_indptr = _as(a_indptr, np.int64, "a_indptr")
         a_indices = _as(a_indices, np.int32, "a_indices")
@@ -267,12 +299,19 @@ class Context:
                     "fdr_knn")
         return idx, dist
 
-    def embed_knn(self, a_indptr, a_indices, k, return_embedding=False):
+    def embed_knn(self, a_indptr, a_indices, k, return_embedding=False, out=None):
+        """out=(idx int32 [n,k], dist float32 [n,k]): caller-owned (e.g. pinned, reused) result arrays."""
         a_indptr = _as(a_indptr, np.int64, "a_indptr")
         a_indices = _as(a_indices, np.int32, "a_indices")
         n = a_indptr.shape[0] - 1
-        idx = np.empty((n, k), dtype=np.int32)
-        dist = np.empty((n, k), dtype=np.float32)
+        if out is None:
+            idx = np.empty((n, k), dtype=np.int32)
+            dist = np.empty((n, k), dtype=np.float32)
+        else:
+            idx, dist = out
+            if (idx.shape, dist.shape) != ((n, k), (n, k)) or idx.dtype != np.int32 or dist.dtype != np.float32 \
+                    or not (idx.flags.c_contiguous and dist.flags.c_contiguous):
+                raise ValueError("out must be C-contiguous (int32 [n,k], float32 [n,k])")
         E = np.empty((n, self.d), dtype=np.float32) if return_embedding else None
         self._check(self._L.fdr_embed_knn(self._h, n, _ptr(a_indptr), _ptr(a_indices), int(k),
                                           _ptr(idx), _ptr(dist), _ptr(E)), "fdr_embed_knn")

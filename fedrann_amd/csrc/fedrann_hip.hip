@@ -22,28 +22,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/fedrann_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned long long u64;
 
-#define FDR_EXPORT extern "C" __attribute__((visibility("default")))
-
-// ------------------------------------------------------------------------------------------
-// error plumbing
-// ------------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char *fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
+#include "host_common.inc"  // error plumbing, FDR_EXPORT, dev_env (plain C++: shared with the sanitizer build)
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -181,6 +169,9 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restr
     }
 }
 
+#include "knn_plan.inc"           // shapes, LDS budgets, target segments (plain C++)
+#include "projection_tables.inc"  // the embed kernel's lookup tables (plain C++)
+#include "csr_compact.inc"        // dead-feature filter (plain C++)
 #include "knn_exact.inc"      // K3 / K4: fp32 MFMA tile kernel with LDS top-k lists, merge
 #include "knn_prefilter.inc"  // P1 / P2: fp16 MFMA candidate pass, merges, certificate + re-rank, range pass
 #include "dedup_classes.inc"  // duplicate-row classes: hash, tables, gathers, expansion
@@ -221,6 +212,7 @@ struct fdr_ctx {
     int d = 0;
     long long p_nnz = 0, p_rows = 0;
     DevBuf ftab, crow, ent;
+    std::vector<uint32_t> h_bits;  // host copy of ftab's bitmap words
     // scratch for the host-pointer API
     DevBuf a_indptr, a_indices, E, Ehat, zero, idx, dist, ws;
     // k-mer search (kmer_search.inc)
@@ -230,6 +222,7 @@ struct fdr_ctx {
     // timing: when enabled, every launch of kernel kind i gets its own hipEvent pair on the launch
     // stream; fdr_timing_read() sums the elapsed times of all launches since the last read
     int knn_mode = FDR_MODE_AUTO;
+    int dedup_mode = FDR_DEDUP_AUTO;
     int last_flagged = 0;  // prefilter mode: queries of the last call that took the exact path
     int last_unique_targets = 0, last_unique_queries = 0;  // duplicate-row classes of the last call
     bool timing = false;
@@ -266,13 +259,7 @@ static int use_device(fdr_ctx *ctx) {
 
 FDR_EXPORT const char *fdr_last_error(void) { return g_err; }
 
-FDR_EXPORT int fdr_padded_dim(int d) {
-    if (d <= 0) return FDR_E_ARG;
-    if (d <= 128) return 128;
-    if (d <= 256) return 256;
-    if (d <= 512) return 512;
-    return FDR_E_ARG;
-}
+FDR_EXPORT int fdr_padded_dim(int d) { return padded_dim(d); }
 
 FDR_EXPORT int fdr_create(int device_id, fdr_ctx **out) {
     if (!out) return fail(FDR_E_ARG, "fdr_create: out is null");
@@ -285,10 +272,19 @@ FDR_EXPORT int fdr_create(int device_id, fdr_ctx **out) {
     fdr_ctx *c = new (std::nothrow) fdr_ctx();
     if (!c) return fail(FDR_E_NOMEM, "out of host memory");
     c->device = device_id;
-    HIP_TRY(hipSetDevice(device_id));
-    HIP_TRY(hipGetDeviceProperties(&c->prop, device_id));
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(FDR_E_HIP, "fdr_create: device %d: %s", device_id, hipGetErrorString(e));
+    }
     c->num_cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // the one environment variable of the release library, read once: the context's initial k-NN mode
+    if (const char *m = getenv("FDR_KNN_MODE")) {
+        if (strcmp(m, "exact") == 0) c->knn_mode = FDR_MODE_EXACT;
+        else if (strcmp(m, "prefilter") == 0) c->knn_mode = FDR_MODE_PREFILTER;
+    }
     *out = c;
     return FDR_OK;
 }
@@ -332,6 +328,12 @@ FDR_EXPORT int fdr_set_knn_mode(fdr_ctx *ctx, int mode) {
     return FDR_OK;
 }
 
+FDR_EXPORT int fdr_set_dedup_mode(fdr_ctx *ctx, int mode) {
+    if (!ctx || mode < FDR_DEDUP_AUTO || mode > FDR_DEDUP_FORCE) return fail(FDR_E_ARG, "bad duplicate-row mode");
+    ctx->dedup_mode = mode;
+    return FDR_OK;
+}
+
 FDR_EXPORT int fdr_timing(fdr_ctx *ctx, int enable) {
     if (!ctx) return fail(FDR_E_ARG, "null context");
     ctx->timing = enable != 0;
@@ -364,46 +366,13 @@ FDR_EXPORT int fdr_projection_load(fdr_ctx *ctx, int64_t n_features, int32_t d,
                                    const float *p_vals) {
     int rc = use_device(ctx);
     if (rc) return rc;
-    if (n_features <= 0 || n_features > 0x7fffffffll || !p_indptr)
-        return fail(FDR_E_ARG, "projection: bad n_features %lld", (long long)n_features);
-    if (fdr_padded_dim(d) < 0)
-        return fail(FDR_E_ARG, "projection: embedding dimension %d unsupported (1..%d)", d,
-                    FDR_MAX_DIM);
+    ProjectionTables T;
+    if ((rc = build_projection_tables(n_features, d, p_indptr, p_cols, p_vals, T))) return rc;
+    const std::vector<PU2> &ftab = T.ftab, &ent = T.ent;
+    const std::vector<PU4> &crow = T.rowinfo;
     const int64_t nnz = p_indptr[n_features];
-    if (p_indptr[0] != 0 || nnz < 0 || nnz > 0x7fffffffll || (nnz > 0 && (!p_cols || !p_vals)))
-        return fail(FDR_E_ARG, "projection: bad CSR arrays");
-    const int64_t nwords = (n_features + 31) / 32;
-    std::vector<uint2> ftab((size_t)nwords);
-    std::vector<uint4> crow;  // rowinfo
-    std::vector<uint2> ent((size_t)std::max<int64_t>(nnz, 1));
-    crow.reserve(1024);
-    unsigned rows = 0;
-    for (int64_t w = 0; w < nwords; ++w) {
-        unsigned bits = 0;
-        const unsigned prefix = rows;
-        const int64_t f0 = w * 32, f1 = std::min<int64_t>(n_features, f0 + 32);
-        for (int64_t f = f0; f < f1; ++f) {
-            const int64_t s = p_indptr[f], e = p_indptr[f + 1];
-            if (e < s || e > nnz) return fail(FDR_E_ARG, "projection: indptr not monotone at %lld", (long long)f);
-            if (e > s) {
-                bits |= 1u << (unsigned)(f - f0);
-                uint32_t fv;
-                memcpy(&fv, &p_vals[s], 4);
-                crow.push_back(make_uint4((unsigned)s, (unsigned)(e - s), (unsigned)p_cols[s], fv));
-                ++rows;
-                for (int64_t q = s; q < e; ++q) {
-                    if (p_cols[q] < 0 || p_cols[q] >= d)
-                        return fail(FDR_E_ARG, "projection: column %d out of range at nnz %lld",
-                                    p_cols[q], (long long)q);
-                    uint32_t vb;
-                    memcpy(&vb, &p_vals[q], 4);
-                    ent[(size_t)q] = make_uint2((unsigned)p_cols[q], vb);
-                }
-            }
-        }
-        ftab[(size_t)w] = make_uint2(bits, prefix);
-    }
-    if (crow.empty()) crow.push_back(make_uint4(0u, 0u, 0u, 0u));
+    const unsigned rows = T.rows;
+    static_assert(sizeof(PU2) == sizeof(uint2) && sizeof(PU4) == sizeof(uint4), "table records = the kernel's uint2 / uint4");
     if ((rc = ctx->ftab.reserve(ftab.size() * sizeof(uint2)))) return rc;
     if ((rc = ctx->crow.reserve(crow.size() * sizeof(uint4)))) return rc;
     if ((rc = ctx->ent.reserve(ent.size() * sizeof(uint2)))) return rc;
@@ -415,6 +384,32 @@ FDR_EXPORT int fdr_projection_load(fdr_ctx *ctx, int64_t n_features, int32_t d,
     ctx->d = d;
     ctx->p_nnz = nnz;
     ctx->p_rows = rows;
+    ctx->h_bits.resize(ftab.size());  // host copy of the bitmap: fdr_csr_compact
+    for (size_t w = 0; w < ftab.size(); ++w) ctx->h_bits[w] = ftab[w].x;
+    return FDR_OK;
+}
+
+FDR_EXPORT int fdr_csr_compact(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr, const int32_t *a_indices,
+                               int64_t *out_indptr, int32_t *out_indices, int64_t out_capacity, int32_t n_threads) {
+    if (!ctx) return fail(FDR_E_ARG, "null context");
+    if (ctx->n_features <= 0) return fail(FDR_E_STATE, "csr_compact: no projection loaded");
+    return csrc::compact(ctx->h_bits, ctx->n_features, n_rows, a_indptr, a_indices, out_indptr, out_indices,
+                         out_capacity, n_threads);
+}
+
+FDR_EXPORT int fdr_host_register(fdr_ctx *ctx, void *ptr, size_t bytes) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (!ptr || bytes == 0) return fail(FDR_E_ARG, "host_register: empty buffer");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return FDR_OK;
+}
+
+FDR_EXPORT int fdr_host_unregister(fdr_ctx *ctx, void *ptr) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (!ptr) return fail(FDR_E_ARG, "host_unregister: null pointer");
+    HIP_TRY(hipHostUnregister(ptr));
     return FDR_OK;
 }
 
@@ -469,217 +464,13 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
     return timing_end(ctx, FDR_KERNEL_NORMALIZE, st);
 }
 
-// Kernel shapes.  queries/workgroup QW = 32*NQ*NW; slots = workgroups resident per CU (LDS- and
-// register-limited).  Shape choice: see knn_choose_shape().
-struct KnnShape {
-    int dp, nq, nw, wps;
-    int tps;  // > 0: fp16 prefilter shape whose LDS ring holds tps one-tile (8 KB) stages
-};
-static const KnnShape kShapes[] = {
-    {128, 1, 4, 3, 0},  // 128 queries/WG, <=168 VGPRs, up to 3 WG/CU
-    {128, 1, 8, 4, 0},  // 256 queries/WG, <=128 VGPRs, up to 2 WG/CU
-    {128, 2, 4, 2, 0},  // 256 queries/WG, <=256 VGPRs, up to 2 WG/CU
-    {256, 1, 8, 2, 0},  // 256 queries/WG, <=256 VGPRs, 1 WG/CU
-    {512, 1, 4, 1, 0},  // 128 queries/WG, one wave per SIMD: 512 registers per lane (256 of them queries)
-    // fp16 prefilter (LDS = the ring only): 128 queries/WG, two-unit stages (32 KB ring).  One-unit
-    // stages (a barrier per 8 MFMAs) cost +25 % at d <= 128, three / four-unit stages lose workgroups per
-    // CU, two query sets per wave (NQ = 2, 192 VGPRs) lost 10-25 % to the lower occupancy.
-    {128, 1, 4, 4, 4},  // d <= 128: <= 128 VGPRs, 4 WG/CU
-    {256, 1, 4, 3, 4},  // d <= 256: <= 168 VGPRs, one tile per stage
-    {512, 1, 4, 2, 4},  // d <= 512: 128 VGPRs of queries, half a tile per stage
-};
-#define FDR_SHAPE_PREFILTER 5  // + 0 / 1 / 2 for d <= 128 / 256 / 512
-static int range_shape(int dp) { return FDR_SHAPE_PREFILTER + (dp == 128 ? 0 : dp == 256 ? 1 : 2); }
-static int prefilter_shape(int dp) { return range_shape(dp); }
-
-static size_t knn_lds_bytes_q(const KnnShape &sh, int k, int qcap) {
-    const size_t qw = (size_t)32 * sh.nq * sh.nw, nt = (size_t)64 * sh.nw;
-    if (sh.tps > 0) return (size_t)sh.tps * 32 * 256;  // fp16 prefilter: the ring only (lists in registers)
-    const size_t ring = (size_t)2 * 32 * 64 * 4;
-    return ring + (size_t)k * qw * 8 + (size_t)qcap * sh.nq * nt * 8;
-}
-
-// Entries per lane append queue: 4, or 2 when that lets one more workgroup share the CU's LDS
-// (co-resident workgroups matter more than the flush rate).
-static int knn_qcap(const KnnShape &sh, int k) {
-    const size_t lds = 160 * 1024;
-    const int with4 = (int)(lds / knn_lds_bytes_q(sh, k, 4)), with2 = (int)(lds / knn_lds_bytes_q(sh, k, 2));
-    const int by_regs = std::max(1, (sh.wps * 4) / sh.nw);
-    return std::min(with2, by_regs) > std::min(with4, by_regs) ? 2 : QCAP;
-}
-
-static size_t knn_lds_bytes(const KnnShape &sh, int k) { return knn_lds_bytes_q(sh, k, knn_qcap(sh, k)); }
-
-static int knn_wg_per_cu(const KnnShape &sh, int k) {
-    const int by_lds = (int)((size_t)160 * 1024 / knn_lds_bytes(sh, k));
-    const int by_regs = (sh.wps * 4) / sh.nw;  // waves per CU the register budget allows / waves per WG
-    return std::max(0, std::min(by_lds, std::max(by_regs, 1)));
-}
-
-static int knn_choose_shape(int dp, int k) {
-    if (const char *e = getenv("FDR_KNN_SHAPE")) {  // development knob: index into kShapes
-        const int i = atoi(e);
-        if (i >= 0 && i < (int)(sizeof(kShapes) / sizeof(kShapes[0])) && kShapes[i].dp == dp &&
-            knn_wg_per_cu(kShapes[i], k) > 0)
-            return i;
-    }
-    if (dp == 256) return 3;
-    if (dp == 512) return 4;
-    // d <= 128: the 4-wave / 128-query shape (no spills at 168 VGPRs, finest work granularity) while
-    // at least two workgroups fit in LDS; for larger k the 2-chain 256-VGPR shape
-    if (knn_wg_per_cu(kShapes[0], k) >= 2) return 0;
-    return 2;
-}
-
-struct KnnPlan {
-    int shape, qw, nqb, nseg, nq_pad;
-    SegBounds segs;
-    size_t bits_bytes;     // packed zero-target flags, at the start of the workspace
-    size_t shared_bytes;   // one cross-segment bound word per (padded) query
-    size_t partial_bytes;  // per-segment top-k lists
-    size_t total_bytes;
-};
-
-// Makespan (in 32-row tiles) of dispatching, in order, nqb workgroups per segment onto `slots`
-// concurrently resident workgroups; every workgroup costs its segment's tiles + `ov` tiles of fixed
-// work (query load, list set-up, final flush and write-out).
-static double simulate_makespan(const std::vector<int> &seg_tiles, int nqb, int slots, double ov) {
-    std::vector<double> heap((size_t)slots, 0.0);  // min-heap of slot free times
-    auto cmp = [](double a, double b) { return a > b; };
-    double last = 0.0;
-    for (int t : seg_tiles)
-        for (int q = 0; q < nqb; ++q) {
-            std::pop_heap(heap.begin(), heap.end(), cmp);
-            const double done = heap.back() + (double)t + ov;
-            heap.back() = done;
-            std::push_heap(heap.begin(), heap.end(), cmp);
-            last = std::max(last, done);
-        }
-    return last;
-}
-
-static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k, int shape);
-
-// the plan search simulates a few hundred dispatch orders: remember the last few results
-struct PlanCacheEntry {
-    int64_t nq, nt;
-    int dp, k, cus, shape;
-    KnnPlan plan;
-};
-static thread_local std::vector<PlanCacheEntry> g_plan_cache;
-
-static KnnPlan knn_plan(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k, int shape = -1) {
-    const int dp = fdr_padded_dim(d);
-    for (const PlanCacheEntry &e : g_plan_cache)
-        if (e.nq == nq && e.nt == nt && e.dp == dp && e.k == k && e.cus == ctx->num_cus && e.shape == shape)
-            return e.plan;
-    PlanCacheEntry e{nq, nt, dp, k, ctx->num_cus, shape, knn_plan_compute(ctx, nq, nt, d, k, shape)};
-    if (g_plan_cache.size() >= 16) g_plan_cache.erase(g_plan_cache.begin());
-    g_plan_cache.push_back(e);
-    if (const char *dbg = getenv("FDR_KNN_DEBUG")) {
-        if (atoi(dbg) & 8) {
-            fprintf(stderr, "[fdr plan] nq=%lld nt=%lld shape=%d nqb=%d nseg=%d tiles:", (long long)nq,
-                    (long long)nt, e.plan.shape, e.plan.nqb, e.plan.nseg);
-            for (int i = 0; i < e.plan.nseg; ++i)
-                fprintf(stderr, " %d", (e.plan.segs.b[i + 1] - e.plan.segs.b[i]) / 32);
-            fprintf(stderr, "\n");
-        }
-    }
-    return e.plan;
-}
-
-static KnnPlan knn_plan_compute(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k, int shape) {
-    KnnPlan p;
-    p.shape = shape >= 0 ? shape : knn_choose_shape(fdr_padded_dim(d), k);
-    const KnnShape &sh = kShapes[p.shape];
-    p.qw = 32 * sh.nq * sh.nw;
-    p.nqb = (int)((nq + p.qw - 1) / p.qw);
-    p.nq_pad = p.nqb * p.qw;
-    // Work split.  The grid is nqb query blocks x nseg target segments; workgroups are dispatched
-    // segment by segment onto `slots` resident workgroups.  Equal segments leave the last "round"
-    // mostly empty whenever nqb * nseg is not just below a multiple of `slots`, so the plan is a few
-    // long segments followed by shorter ones that fill the tail (guided self-scheduling), chosen by
-    // simulating the dispatch.  Segments of one query block share their bound (topk_share), so the
-    // extra segments cost little more than their fixed set-up (`ov`, in tiles).
-    int slots = ctx->num_cus * std::max(1, knn_wg_per_cu(sh, k));
-    // fp16 prefilter: a fourth workgroup on a CU hides latency but shares the same MFMA / LDS pipes; the
-    // dispatch model that matched the measurements best counts three (100 k rows: 3.3 ms vs 3.9 ms)
-    if (sh.tps > 0) slots = std::min(slots, ctx->num_cus * 3);
-    if (const char *e = getenv("FDR_KNN_SLOTS")) slots = ctx->num_cus * std::max(1, atoi(e));  // development knob
-    const int T = (int)((nt + 31) / 32);  // tiles
-    double ov = sh.tps > 0 ? 96.0 : 16.0;  // fp16 tiles are 16x shorter: the fixed cost weighs more
-    if (const char *e = getenv("FDR_KNN_OV")) ov = atof(e);  // development knob
-    // fp16 prefilter keys index rows inside a segment with at most FDR_PREFILTER_MAX_IB bits
-    const int cap_tiles = sh.tps > 0 ? (1 << FDR_PREFILTER_MAX_IB) / 32 : T;
-    std::vector<int> best;
-    {
-        const int c0 = (T + cap_tiles - 1) / cap_tiles, l0 = (T + c0 - 1) / c0;
-        for (int left = T; left > 0; left -= l0) best.push_back(std::min(left, l0));
-    }
-    double best_cost = simulate_makespan(best, p.nqb, slots, ov);
-    const int min_tiles = sh.tps > 0 ? 128 : 24;  // never cut segments shorter than 768 (4096) rows
-    for (int cmain = 1; cmain <= 24; ++cmain)
-        for (int tf = 0; tf <= 4; ++tf)          // share of the tiles given to the short tail
-            for (int div = 2; div <= 8; div *= 2) {  // tail segments are 1/div of a main segment
-                const double tail_frac = 0.08 * tf;
-                if (tf == 0 && div != 2) continue;
-                const int main_total = (int)((1.0 - tail_frac) * T);
-                const int lm = std::max(min_tiles, (main_total + cmain - 1) / cmain);
-                std::vector<int> segs;
-                int left = T;
-                for (int i = 0; i < cmain && left > 0; ++i) {
-                    const int t = std::min(left, lm);
-                    segs.push_back(t);
-                    left -= t;
-                }
-                const int ls = std::max(min_tiles, lm / div);
-                while (left > 0) {
-                    const int t = (left < ls + min_tiles) ? left : ls;
-                    segs.push_back(t);
-                    left -= t;
-                }
-                if ((int)segs.size() > FDR_MAX_SEG) continue;
-                if (*std::max_element(segs.begin(), segs.end()) > cap_tiles) continue;
-                const double cost = simulate_makespan(segs, p.nqb, slots, ov);
-                if (cost < best_cost * 0.999) {
-                    best_cost = cost;
-                    best = segs;
-                }
-            }
-    if (const char *e = getenv("FDR_KNN_NSEG")) {  // development knob: nseg equal segments
-        const int c = std::max(1, std::min(atoi(e), FDR_MAX_SEG));
-        if (atoi(e) > 0) {
-            best.clear();
-            const int l = (T + c - 1) / c;
-            for (int left = T; left > 0; left -= l) best.push_back(std::min(left, l));
-        }
-    }
-    p.nseg = (int)best.size();
-    int row = 0;
-    for (int i = 0; i < p.nseg; ++i) {
-        p.segs.b[i] = row;
-        row += best[(size_t)i] * 32;
-    }
-    for (int i = p.nseg; i <= FDR_MAX_SEG; ++i) p.segs.b[i] = row;
-    p.partial_bytes = (size_t)p.nseg * p.nq_pad * (size_t)k * sizeof(u64);
-    p.bits_bytes = ((size_t)((nt + 31) / 32) * 4 + 255) / 256 * 256;
-    p.shared_bytes = ((size_t)p.nq_pad * 4 + 255) / 256 * 256;
-    p.total_bytes = p.bits_bytes + p.shared_bytes + p.partial_bytes;
-    return p;
-}
-
 static size_t knn_workspace_bytes_impl(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k);
 
 // ---- prefilter mode: workspace layout -------------------------------------------------------
 // mode: FDR_MODE_AUTO uses the fp16 prefilter whenever it applies (d <= 128, k + 8 <= 64) and the
 // target set is large enough to pay for it; FDR_KNN_MODE=exact|prefilter|auto overrides the context.
 static bool knn_prefilter_wanted(const fdr_ctx *ctx, int dp, int64_t nt, int k) {
-    int mode = ctx->knn_mode;
-    if (const char *e = getenv("FDR_KNN_MODE")) {
-        if (strcmp(e, "exact") == 0) mode = FDR_MODE_EXACT;
-        else if (strcmp(e, "prefilter") == 0) mode = FDR_MODE_PREFILTER;
-        else if (strcmp(e, "auto") == 0) mode = FDR_MODE_AUTO;
-    }
+    const int mode = ctx->knn_mode;
     if (mode == FDR_MODE_EXACT) return false;
     const int kp = (k + prefilter_extra() + 1) & ~1;
     if (!(kp <= FDR_MAX_K && nt >= kp)) return false;
@@ -701,9 +492,9 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     PrefilterLayout L;
     L.kp = (k + prefilter_extra() + 1) & ~1;
     L.chunk = (int)std::min<int64_t>(nq, 16384);
-    const size_t exact_all = knn_plan(ctx, nq, nt, d, k).total_bytes;
+    const size_t exact_all = knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
     const int dp = fdr_padded_dim(d);
-    const size_t pre = knn_plan(ctx, nq, nt, d, L.kp, prefilter_shape(dp)).total_bytes;
+    const size_t pre = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp)).total_bytes;
     // any exact plan for <= chunk queries: bits + bound words + at most FDR_MAX_SEG segments of lists
     const size_t chunk_bound = align256((size_t)((nt + 31) / 32) * 4) + align256((size_t)(L.chunk + 128) * 4) +
                                (size_t)FDR_MAX_SEG * (L.chunk + 128) * (size_t)k * 8;
@@ -748,7 +539,7 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
     if (nq == 0) return FDR_OK;
     if (!d_Qhat || !d_qzero || !d_That || !d_tzero || !d_idx || !d_dist || !d_ws)
         return fail(FDR_E_ARG, "knn: null device pointer");
-    const KnnPlan p = knn_plan(ctx, nq, nt, d, k);
+    const KnnPlan p = knn_plan(ctx->num_cus, nq, nt, d, k);
     if (ws_bytes < p.total_bytes)
         return fail(FDR_E_ARG, "knn: workspace %zu < required %zu bytes", ws_bytes, p.total_bytes);
     unsigned *d_bits = reinterpret_cast<unsigned *>(d_ws);
@@ -761,8 +552,8 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
     const size_t lds = knn_lds_bytes(sh, k);
     if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn: k=%d, d=%d needs %zu B of LDS (> 160 KiB)", k, d, lds);
     dim3 grid((unsigned)p.nqb, (unsigned)p.nseg);
-    const char *dbg_env = getenv("FDR_KNN_DEBUG");  // development knob, see DESIGN.md
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    const int dbg = dev_env_int("FDR_KNN_DEBUG", 0);  // development knob (-DFDR_DEV builds only)
+    (void)dbg;
     int trc = timing_begin(ctx, FDR_KERNEL_KNN_TILE, st);
     if (trc) return trc;
 #define FDR_LAUNCH_KNN(DP_, NQ_, NW_, WPS_)                                                          \
@@ -771,7 +562,7 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
         hipLaunchKernelGGL((knn_tile_kernel<DP_, NQ_, NW_, WPS_>), grid, dim3(64 * NW_), lds, st, d_Qhat, \
                            d_qzero, (int)nq, d_That, d_bits, (int)nt, (int)t_base, p.segs, k,        \
-                           p.nq_pad, d_partial, d_shared, knn_qcap(sh, k), dbg);                     \
+                           p.nq_pad, d_partial, d_shared, knn_qcap(sh, k) FDR_DBG_ARG(dbg));        \
     } while (0)
     switch (p.shape) {
         case 0: FDR_LAUNCH_KNN(128, 1, 4, 3); break;
@@ -822,7 +613,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     const int kp = L.kp;
 
     const int dp = fdr_padded_dim(d);
-    const KnnPlan p = knn_plan(ctx, nq, nt, d, kp, prefilter_shape(dp));
+    const KnnPlan p = knn_plan(ctx->num_cus, nq, nt, d, kp, prefilter_shape(dp));
     const KnnShape &sh = kShapes[prefilter_shape(dp)];
     unsigned *d_bits = reinterpret_cast<unsigned *>(ws);
     unsigned *d_shared = reinterpret_cast<unsigned *>(ws + p.bits_bytes);
@@ -844,25 +635,29 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if (ib > FDR_PREFILTER_MAX_IB) return fail(FDR_E_ARG, "knn prefilter: segment of %d rows", max_seg);
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
-    const int pdbg = getenv("FDR_KNN_DEBUG") ? atoi(getenv("FDR_KNN_DEBUG")) : 0;
+    const int pdbg = dev_env_int("FDR_KNN_DEBUG", 0);
+    (void)pdbg;
 #define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_)                                                   \
     do { /* (the ring is at most 32 KB: no dynamic-LDS attribute needed) */                             \
         hipLaunchKernelGGL((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>),                        \
                            dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(64 * NW_), lds, st, d_hq, (int)nq, \
-                           d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, d_shared, ib,   \
-                           pdbg);                                                                       \
+                           d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, d_shared, ib    \
+                           FDR_DBG_ARG(pdbg));                                                          \
     } while (0)
 #define FDR_LAUNCH_PRE(DP_, NQ_, NW_, WPS_, U_)                                                         \
     do {                                                                                                \
         if (kp <= 32) FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 16);                                     \
         else FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 32);                                              \
     } while (0)
-    if (dp == 128 && kp <= 32 && !(getenv("FDR_KNN_PAIR") && atoi(getenv("FDR_KNN_PAIR")) == 0)) {
+    if (prefilter_shape(dp) == 8) {
+        if (kp <= 32) FDR_LAUNCH_PRE2(128, 2, 4, 2, 2, 16);
+        else FDR_LAUNCH_PRE2(128, 2, 4, 2, 2, 32);
+    } else if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_PAIR", 1) != 0) {
         // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
         // <= 128 VGPRs.  FDR_KNN_PAIR=0: development knob, one chain)
         hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)p.nqb, (unsigned)p.nseg),
                            dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad,
-                           d_partial, d_shared, ib, pdbg);
+                           d_partial, d_shared, ib FDR_DBG_ARG(pdbg));
     } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
     else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
     else FDR_LAUNCH_PRE(512, 1, 4, 2, 2);
@@ -889,7 +684,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     HIP_TRY(hipMemsetAsync(d_counter, 0, 16, st));
     int *d_rlist = reinterpret_cast<int *>(ws + L.off_rlist);
     float *d_theta = reinterpret_cast<float *>(ws + L.off_theta);
-    const bool use_range = !(getenv("FDR_KNN_RANGE") && atoi(getenv("FDR_KNN_RANGE")) == 0);  // dev knob
+    const bool use_range = dev_env_int("FDR_KNN_RANGE", 1) != 0;  // dev knob
     const float margin = 2.0f * prefilter_eps(ib) + 4.0e-7f;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
                        (const u64 *)d_cand, kp, k, d_Qhat, d_qzero, d_That, (int)nq, dp, (int)t_base, margin,
@@ -926,7 +721,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                                (const _Float16 *)d_hq, (const float *)d_theta, (const int *)d_rlist, first, c,
                                dp, d_hqc, d_thetac, d_cnt);
             HIP_TRY(hipGetLastError());
-            const KnnPlan rp = knn_plan(ctx, c, nt, d, 1, range_shape(dp));  // (k = 1: ring-only LDS)
+            const KnnPlan rp = knn_plan(ctx->num_cus, c, nt, d, 1, range_shape(dp));  // (k = 1: ring-only LDS)
             const size_t rlds = (size_t)2 * 32 * 256;
 #define FDR_LAUNCH_RANGE(DP_, WPS_)                                                                     \
     hipLaunchKernelGGL((knn_range_kernel<DP_, 4, WPS_>), dim3((unsigned)rp.nqb, (unsigned)rp.nseg),        \
@@ -970,7 +765,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
 
 static size_t knn_mode_workspace_bytes(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
     if (knn_prefilter_wanted(ctx, fdr_padded_dim(d), nt, k)) return prefilter_layout(ctx, nq, nt, d, k).total;
-    return knn_plan(ctx, nq, nt, d, k).total_bytes;
+    return knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
 }
 
 static int launch_knn_mode(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
@@ -994,8 +789,8 @@ struct DedupLayout {
         off_distu, off_tmp, tmp_bytes, total;
 };
 
-static bool knn_dedup_wanted(int64_t nq, int64_t nt) {
-    if (const char *e = getenv("FDR_KNN_DEDUP")) return atoi(e) != 0;  // development knob
+static bool knn_dedup_wanted(const fdr_ctx *ctx, int64_t nq, int64_t nt) {
+    if (ctx->dedup_mode != FDR_DEDUP_AUTO) return ctx->dedup_mode != FDR_DEDUP_OFF;
     return nt >= 8192 && nq >= 1024;  // (from the size at which the prefilter mode engages)
 }
 
@@ -1044,7 +839,7 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     const bool q_in_t = d_Qhat && d_That && dp > 0 && d_Qhat >= d_That &&
                         d_Qhat + (size_t)nq * dp <= d_That + (size_t)nt * dp &&
                         ((d_Qhat - d_That) % dp) == 0;
-    if (!(dp > 0 && k >= 1 && k <= FDR_MAX_K && nq > 0 && nt >= k && q_in_t && knn_dedup_wanted(nq, nt) &&
+    if (!(dp > 0 && k >= 1 && k <= FDR_MAX_K && nq > 0 && nt >= k && q_in_t && knn_dedup_wanted(ctx, nq, nt) &&
           d_qzero && d_tzero && d_idx && d_dist && d_ws)) {
         ctx->last_unique_targets = (int)nt;
         ctx->last_unique_queries = (int)nq;
@@ -1072,8 +867,7 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     if (trc) return trc;
     hipLaunchKernelGGL(hash_rows_kernel, dim3(g16), dim3(256), 0, st, d_That, n, dp, hash, idx);
     HIP_TRY(hipGetLastError());
-    const char *knob = getenv("FDR_KNN_DEDUP");
-    const bool always = knob && atoi(knob) == 2;  // development knob: expand even without duplicates
+    const bool always = ctx->dedup_mode == FDR_DEDUP_FORCE;  // expand even without duplicates (tests)
     if (!always) {
         // a hash-table probe (~15 us) tells whether enough rows repeat to pay for the sort and the tables;
         // the table borrows the (still unused) unique-row buffer
@@ -1152,7 +946,7 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
 }
 
 static size_t knn_workspace_bytes_impl(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
-    if (knn_dedup_wanted(nq, nt)) return dedup_layout(ctx, nq, nt, d, k).total;
+    if (knn_dedup_wanted(ctx, nq, nt)) return dedup_layout(ctx, nq, nt, d, k).total;
     return knn_mode_workspace_bytes(ctx, nq, nt, d, k);
 }
 

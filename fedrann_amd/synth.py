@@ -8,59 +8,89 @@ are U{2..2c}, shared by f and f + L.  With doubling=True row 2i is the read and 
 strand mirror (the reference's behaviour, feature_extraction.py:136-140); with doubling=False one
 row per read.  No row is empty.
 """
+import os
+
 import numpy as np
 
 
+def _synth_chunk(args):
+    """Rows of reads [r0, r0 + n): every chunk has its own generator, seeded by (seed, chunk number), so any
+    row range can be generated without the rows before it (rank-local generation, threads)."""
+    seed, cid, r0, n, L, m, q, sigma, doubling, perm = args
+    F = 2 * L
+    rng = np.random.default_rng([seed, 1 + cid])
+    start = rng.integers(0, L, size=n)
+    length = np.maximum(4, rng.lognormal(np.log(m) - sigma * sigma / 2, sigma, size=n)).astype(np.int64)
+    length = np.minimum(length, L)
+    flip = rng.random(n) < 0.5
+    T = int(length.sum())
+    row = np.repeat(np.arange(n, dtype=np.int64), length)
+    first = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(length, out=first[1:])
+    off = np.arange(T, dtype=np.int64) - np.repeat(first[:-1], length)
+    keep = rng.random(T) < q
+    kept_per_row = np.bincount(row[keep], minlength=n)
+    keep[first[:-1][kept_per_row == 0]] = True  # at least one slot survives
+    row, off = row[keep], off[keep]
+    slot = (start[row] + off) % L
+    feat = perm[slot] + np.where(flip[row], L, 0)
+    if doubling:
+        mirror = np.where(feat < L, feat + L, feat - L)
+        row = np.concatenate((2 * row, 2 * row + 1))
+        feat = np.concatenate((feat, mirror))
+        nrows = 2 * n
+    else:
+        nrows = n
+    key = row * np.int64(F) + feat
+    key.sort()
+    row_s = key // np.int64(F)
+    return (key - row_s * np.int64(F)).astype(np.int32), np.bincount(row_s, minlength=nrows)
+
+
 def synth(R, seed=602, m=200, q=0.85, c=30, Lcap=12_500_000, sigma=0.5, doubling=False,
-          chunk=100_000):
+          chunk=100_000, reads=None, threads=None):
     """Returns dict(indptr int64, indices int32 (ascending per row), n_features, counts int64 [L],
-    names list[str], strands list[int])."""
-    rng = np.random.default_rng(seed)
+    names list[str], strands list[int]).  reads=(lo, hi): only the rows of reads [lo, hi) (lo a multiple
+    of `chunk`; indptr rebased to 0) -- what one rank of a row-sharded run needs; the genome (perm),
+    the counts and every read are the same whichever range is asked for."""
+    rng = np.random.default_rng([seed, 0])
     L = int(min(max(R * m // c, 64), Lcap))
     F = 2 * L
     perm = rng.permutation(L).astype(np.int64)
     counts = rng.integers(2, 2 * c + 1, size=L).astype(np.int64)
-    ip_parts, ix_parts = [np.zeros(1, dtype=np.int64)], []
-    total = 0
-    for r0 in range(0, R, chunk):
-        n = min(chunk, R - r0)
-        start = rng.integers(0, L, size=n)
-        length = np.maximum(4, rng.lognormal(np.log(m) - sigma * sigma / 2, sigma, size=n)).astype(np.int64)
-        length = np.minimum(length, L)
-        flip = rng.random(n) < 0.5
-        T = int(length.sum())
-        row = np.repeat(np.arange(n, dtype=np.int64), length)
-        first = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum(length, out=first[1:])
-        off = np.arange(T, dtype=np.int64) - np.repeat(first[:-1], length)
-        keep = rng.random(T) < q
-        kept_per_row = np.bincount(row[keep], minlength=n)
-        keep[first[:-1][kept_per_row == 0]] = True  # at least one slot survives
-        row, off = row[keep], off[keep]
-        slot = (start[row] + off) % L
-        feat = perm[slot] + np.where(flip[row], L, 0)
-        if doubling:
-            mirror = np.where(feat < L, feat + L, feat - L)
-            row = np.concatenate((2 * row, 2 * row + 1))
-            feat = np.concatenate((feat, mirror))
-            nrows = 2 * n
-        else:
-            nrows = n
-        key = row * np.int64(F) + feat
-        key.sort()
-        row_s = key // np.int64(F)
-        ix_parts.append((key - row_s * np.int64(F)).astype(np.int32))
-        cnt = np.bincount(row_s, minlength=nrows)
+    lo, hi = (0, R) if reads is None else (int(reads[0]), int(reads[1]))
+    if lo % chunk or not (0 <= lo <= hi <= R):
+        raise ValueError("reads=(lo, hi): lo must be a multiple of chunk=%d and 0 <= lo <= hi <= R" % chunk)
+    jobs = []
+    for r0 in range(lo, hi, chunk):
+        full = min(chunk, R - r0)  # a chunk is always generated whole (its generator is consumed in order)
+        jobs.append((seed, r0 // chunk, r0, full, L, m, q, sigma, doubling, perm))
+    if threads is None:
+        threads = min(16, len(os.sched_getaffinity(0)))
+    if len(jobs) > 1 and threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as ex:  # numpy's sort and RNG release the GIL
+            parts = list(ex.map(_synth_chunk, jobs))
+    else:
+        parts = [_synth_chunk(j) for j in jobs]
+    per = 2 if doubling else 1
+    ip_parts, ix_parts, total = [np.zeros(1, dtype=np.int64)], [], 0
+    for job, (ix, cnt) in zip(jobs, parts):
+        want = (min(hi, job[2] + job[3]) - job[2]) * per  # the last chunk may be cut by hi
+        if want < cnt.size:
+            cnt = cnt[:want]
+            ix = ix[:int(cnt.sum())]
+        ix_parts.append(ix)
         ip_parts.append(total + np.cumsum(cnt))
         total += int(cnt.sum())
     indptr = np.concatenate(ip_parts).astype(np.int64)
     indices = np.concatenate(ix_parts) if ix_parts else np.zeros(0, np.int32)
     if doubling:
-        names = ["read_%d" % i for i in range(R) for _ in (0, 1)]
-        strands = [0, 1] * R
+        names = ["read_%d" % i for i in range(lo, hi) for _ in (0, 1)]
+        strands = [0, 1] * (hi - lo)
     else:
-        names = ["read_%d" % i for i in range(R)]
-        strands = [0] * R
+        names = ["read_%d" % i for i in range(lo, hi)]
+        strands = [0] * (hi - lo)
     return {"indptr": indptr, "indices": indices, "n_features": F, "counts": counts,
             "names": names, "strands": strands}
 

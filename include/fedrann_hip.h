@@ -61,6 +61,22 @@ int fdr_padded_dim(int d);
 int fdr_projection_load(fdr_ctx *ctx, int64_t n_features, int32_t d, const int64_t *p_indptr,
                         const int32_t *p_cols, const float *p_vals);
 
+/* Drop the column ids of a read x feature CSR whose projection row is empty (host only; needs a loaded
+ * projection).  P's density is 1/sqrt(F) (precompute.py:80-84): >= 90 % of the features have no entry in P
+ * and add nothing to A.dot(P) (feature_extraction.py:204-213), so a caller that compacts its CSR before
+ * fdr_embed / fdr_embed_knn moves ~10x fewer bytes over PCIe; E is bit for bit the same (the surviving
+ * ids keep their order).  out_indptr int64 [n_rows + 1]; out_indices int32 with room for out_capacity ids
+ * (a_indptr[n_rows] always suffices); the outputs must not alias the inputs.  n_threads <= 0: all
+ * hardware threads. */
+int fdr_csr_compact(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr, const int32_t *a_indices,
+                    int64_t *out_indptr, int32_t *out_indices, int64_t out_capacity, int32_t n_threads);
+
+/* Pin / unpin caller-owned host memory (hipHostRegister) so that the host-pointer calls below copy at PCIe
+ * rate instead of through a staging buffer.  The caller still owns the memory and must unpin it before
+ * freeing it. */
+int fdr_host_register(fdr_ctx *ctx, void *ptr, size_t bytes);
+int fdr_host_unregister(fdr_ctx *ctx, void *ptr);
+
 /* ---- E = A . P  (replaces process_read_chunk_optimized + the scatter loop,
  *      feature_extraction.py:167-213, :280-290) --------------------------------------------
  * A is the binary read x feature CSR: a_indptr int64[n_rows+1], a_indices int32[nnz], column ids
@@ -125,13 +141,23 @@ int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out
  * query; a certificate proves they contain the exact top-k and their distances are recomputed with
  * the canonical fp32 chain; queries that cannot be certified are searched by the exact kernel.  The
  * prefilter mode reads one 4-byte counter back per call (a stream synchronisation).  AUTO (default):
- * PREFILTER when it applies and there are >= 8192 targets.  The environment variable
- * FDR_KNN_MODE=exact|prefilter|auto overrides the context's setting. */
+ * PREFILTER when it applies and there are >= 8192 targets.  A new context starts in the mode named by
+ * the environment variable FDR_KNN_MODE=exact|prefilter|auto (read once, in fdr_create; default auto) --
+ * the only environment variable the library reads. */
 #define FDR_MODE_AUTO 0
 #define FDR_MODE_EXACT 1
 #define FDR_MODE_PREFILTER 2
 int fdr_set_knn_mode(fdr_ctx *ctx, int mode);
-/* Duplicate-row classes: unique target / query rows the most recent k-NN call
+/* Duplicate-row classes: bitwise-identical rows are searched once and the result
+ * expanded -- the same canonical result either way.  AUTO (default): from 8192 targets, when at least 5 % of
+ * the rows repeat.  OFF: never.  ON: at every size (same 5 % test).  FORCE: always expand, even without
+ * duplicates (the parity tests' "+classes" variants). */
+#define FDR_DEDUP_AUTO 0
+#define FDR_DEDUP_OFF 1
+#define FDR_DEDUP_ON 2
+#define FDR_DEDUP_FORCE 3
+int fdr_set_dedup_mode(fdr_ctx *ctx, int mode);
+/* Unique target / query rows the most recent k-NN call
  * actually searched (= the row counts when the call found too few duplicates to bother). */
 int fdr_last_unique(fdr_ctx *ctx, int *unique_targets, int *unique_queries);
 /* Prefilter mode only: number of query rows of the most recent k-NN call whose candidate set could
@@ -171,13 +197,15 @@ int fdr_kmer_count_fetch(fdr_ctx *ctx, uint64_t *codes_out, uint64_t *counts_out
  * Row 2r = record r, row 2r + 1 = its mirror.  Two calls, caller-allocated outputs:
  *   fdr_kmer_output_scan: record count R, sum of index counts nnz, sum of id lengths;
  *   fdr_kmer_output_load: indptr int64 [2R + 1], indices int32 [2 nnz], name_off int64 [R + 1],
- *                         names [name_bytes] (raw id bytes, record r at name_off[r] .. name_off[r+1]).
+ *                         names [name_bytes] (raw id bytes, record r at name_off[r] .. name_off[r+1]);
+ *                         n_records / nnz / name_bytes = the scan's results the arrays were sized from
+ *                         (FDR_E_STATE if the file no longer matches them: nothing is written then).
  * n_threads <= 0: all hardware threads.  Errors as in the reference (bad magic / version, short
  * header -> FDR_E_ARG), plus truncated records, indices outside [0, n_features) and repeated indices
  * inside a record (the reference would sum them; kmer_searcher emits sets). */
 int fdr_kmer_output_scan(const char *path, int64_t *n_records, int64_t *nnz, int64_t *name_bytes);
-int fdr_kmer_output_load(const char *path, int64_t n_features, int32_t n_threads, int64_t *indptr,
-                         int32_t *indices, int64_t *name_off, char *names);
+int fdr_kmer_output_load(const char *path, int64_t n_features, int32_t n_threads, int64_t n_records, int64_t nnz,
+                         int64_t name_bytes, int64_t *indptr, int32_t *indices, int64_t *name_off, char *names);
 
 #ifdef __cplusplus
 }

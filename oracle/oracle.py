@@ -208,6 +208,13 @@ def knn(E, k, q_lo=0, q_hi=None):
     return knn_normalized(Eh[q_lo:q_hi], zero[q_lo:q_hi], Eh, zero, k)
 
 
+def pair_dist_normalized(a, a_zero, b, b_zero):
+    """Canonical distance of two NORMALISED rows (fp32 fma chain, clamp, zero-row rules)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return float(lib().orc_pair_dist(_p(a), _p(b), len(a), int(a_zero), int(b_zero)))
+
+
 def pair_dist(a, b):
     a = np.ascontiguousarray(a, dtype=np.float32)
     b = np.ascontiguousarray(b, dtype=np.float32)

@@ -1,0 +1,211 @@
+// Host-only build of the library's plain-C++ parts under AddressSanitizer + UBSan (never the GPU build):
+//   kmer_output_loader.inc (output.bin -> CSR), projection_tables.inc (the embed kernel's lookup tables),
+//   csr_compact.inc (dead-feature filter), knn_plan.inc (launch planner).
+// tests/test_host_san.py builds this with g++ -fsanitize=address,undefined and drives it; each command
+// prints a result line that the test compares with what libfedrann_hip.so returns for the same input.
+//
+//   host_san loader PATH N_FEATURES THREADS       -> "rc=<code> R=.. nnz=.. sums=<4 weighted sums>" | "rc=<code> err=<msg>"
+//   host_san loader-stale PATH N_FEATURES         -> load with capacities that no longer match: must fail cleanly
+//   host_san tables SEED N_FEATURES D             -> builds tables for a random very-sparse P, checks them, compacts a CSR
+//   host_san plan-print NQ NT D K SHAPE           -> one plan (devtools)
+//   host_san plan                                 -> sweeps the planner over edge sizes, checks invariants
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/fedrann_hip.h"
+#include "../../fedrann_amd/csrc/host_common.inc"
+#include "../../fedrann_amd/csrc/knn_plan.inc"
+#include "../../fedrann_amd/csrc/projection_tables.inc"
+#include "../../fedrann_amd/csrc/csr_compact.inc"
+#include "../../fedrann_amd/csrc/kmer_output_loader.inc"
+
+template <typename T>
+static uint64_t wsum(const std::vector<T> &v) {  // sum of (i + 1) * v[i] mod 2^64 (numpy can restate it)
+    uint64_t s = 0;
+    for (size_t i = 0; i < v.size(); ++i)
+        s += (uint64_t)(i + 1) * (uint64_t)(typename std::make_unsigned<T>::type)v[i];
+    return s;
+}
+
+static int cmd_loader(const char *path, long long F, int threads, bool stale) {
+    int64_t R = 0, nnz = 0, nb = 0;
+    int rc = fdr_kmer_output_scan(path, &R, &nnz, &nb);
+    if (rc) {
+        printf("rc=%d err=%s\n", rc, g_err);
+        return 0;
+    }
+    std::vector<int64_t> indptr((size_t)(2 * R + 1)), name_off((size_t)(R + 1));
+    std::vector<int32_t> indices((size_t)(2 * nnz));
+    std::vector<char> names((size_t)nb);
+    rc = fdr_kmer_output_load(path, F, threads, stale ? R + 1 : R, nnz, nb, indptr.data(), indices.data(),
+                              name_off.data(), names.data());
+    if (rc) {
+        printf("rc=%d err=%s\n", rc, g_err);
+        return 0;
+    }
+    printf("rc=0 R=%lld nnz=%lld sums=%llu,%llu,%llu,%llu\n", (long long)R, (long long)nnz,
+           (unsigned long long)wsum(indptr), (unsigned long long)wsum(indices), (unsigned long long)wsum(name_off),
+           (unsigned long long)wsum(names));
+    return 0;
+}
+
+static int cmd_tables(unsigned seed, long long F, int d) {
+    std::mt19937_64 rng(seed);
+    // a very sparse P: each feature row is non-empty with probability ~ d / sqrt(F) (capped), 1-3 entries
+    std::vector<int64_t> indptr((size_t)F + 1, 0);
+    std::vector<int32_t> cols;
+    std::vector<float> vals;
+    const double p = std::min(0.5, (double)d / std::sqrt((double)F));
+    for (long long f = 0; f < F; ++f) {
+        if ((rng() >> 11) * (1.0 / 9007199254740992.0) < p) {
+            const int n = 1 + (int)(rng() % 3);
+            for (int i = 0; i < n; ++i) {
+                cols.push_back((int32_t)(rng() % (unsigned)d));
+                vals.push_back((float)((int)(rng() % 2001) - 1000) / 256.0f);
+            }
+        }
+        indptr[(size_t)f + 1] = (int64_t)cols.size();
+    }
+    ProjectionTables T;
+    int rc = build_projection_tables(F, d, indptr.data(), cols.data(), vals.data(), T);
+    if (rc) {
+        printf("rc=%d err=%s\n", rc, g_err);
+        return 1;
+    }
+    // invariants: bit <=> non-empty row, prefix counts, rowinfo mirrors the CSR
+    unsigned rows = 0;
+    for (long long f = 0; f < F; ++f) {
+        const bool bit = (T.ftab[(size_t)(f >> 5)].x >> (f & 31)) & 1u;
+        const bool nonempty = indptr[(size_t)f + 1] > indptr[(size_t)f];
+        if (bit != nonempty) return printf("FAIL bit %lld\n", f), 1;
+        if ((f & 31) == 0 && T.ftab[(size_t)(f >> 5)].y != rows) return printf("FAIL prefix %lld\n", f), 1;
+        if (nonempty) {
+            const PU4 &ri = T.rowinfo[rows++];
+            if (ri.x != (unsigned)indptr[(size_t)f] || ri.y != (unsigned)(indptr[(size_t)f + 1] - indptr[(size_t)f]) ||
+                ri.z != (unsigned)cols[(size_t)indptr[(size_t)f]])
+                return printf("FAIL rowinfo %lld\n", f), 1;
+        }
+    }
+    if (rows != T.rows) return printf("FAIL rows\n"), 1;
+    // bad inputs must be refused, not read out of bounds
+    {
+        std::vector<int64_t> bad = indptr;
+        bad[(size_t)F / 2] = bad[(size_t)F] + 5;
+        ProjectionTables U;
+        if (build_projection_tables(F, d, bad.data(), cols.data(), vals.data(), U) == FDR_OK) return printf("FAIL monotone\n"), 1;
+        if (!cols.empty()) {
+            std::vector<int32_t> bc = cols;
+            bc[bc.size() / 2] = d;
+            if (build_projection_tables(F, d, indptr.data(), bc.data(), vals.data(), U) == FDR_OK) return printf("FAIL column\n"), 1;
+        }
+        if (build_projection_tables(F, 513, indptr.data(), cols.data(), vals.data(), U) == FDR_OK) return printf("FAIL dim\n"), 1;
+    }
+    // compaction of a random CSR (incl. empty rows, ids outside [0, F)) at 1 and 5 threads == a serial filter
+    std::vector<uint32_t> bits(T.ftab.size());
+    for (size_t w = 0; w < bits.size(); ++w) bits[w] = T.ftab[w].x;
+    const int64_t n_rows = 20000;
+    std::vector<int64_t> a_ip((size_t)n_rows + 1, 0);
+    std::vector<int32_t> a_ix;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int n = (r % 97 == 0) ? 0 : (int)(rng() % 300);
+        std::vector<int32_t> row;
+        for (int i = 0; i < n; ++i) row.push_back((int32_t)(rng() % (uint64_t)(F + (r % 1013 == 0 ? 7 : 0))));
+        std::sort(row.begin(), row.end());
+        a_ix.insert(a_ix.end(), row.begin(), row.end());
+        a_ip[(size_t)r + 1] = (int64_t)a_ix.size();
+    }
+    std::vector<int64_t> want_ip((size_t)n_rows + 1, 0);
+    std::vector<int32_t> want_ix;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        for (int64_t q = a_ip[(size_t)r]; q < a_ip[(size_t)r + 1]; ++q) {
+            const int64_t f = a_ix[(size_t)q];
+            if (f < F && indptr[(size_t)f + 1] > indptr[(size_t)f]) want_ix.push_back((int32_t)f);
+        }
+        want_ip[(size_t)r + 1] = (int64_t)want_ix.size();
+    }
+    for (int threads : {1, 5}) {
+        std::vector<int64_t> o_ip((size_t)n_rows + 1);
+        std::vector<int32_t> o_ix(want_ix.size());  // exactly enough room: one more write would be caught
+        rc = csrc::compact(bits, F, n_rows, a_ip.data(), a_ix.data(), o_ip.data(), o_ix.data(), (int64_t)o_ix.size(), threads);
+        if (rc || o_ip != want_ip || o_ix != want_ix) return printf("FAIL compact threads=%d rc=%d\n", threads, rc), 1;
+        if (!want_ix.empty() &&
+            csrc::compact(bits, F, n_rows, a_ip.data(), a_ix.data(), o_ip.data(), o_ix.data(), (int64_t)o_ix.size() - 1, threads) == FDR_OK)
+            return printf("FAIL capacity\n"), 1;
+    }
+    printf("rc=0 rows=%u nnz=%zu kept=%zu of %zu\n", T.rows, cols.size(), want_ix.size(), a_ix.size());
+    return 0;
+}
+
+static int check_plan(int cus, int64_t nq, int64_t nt, int d, int k, int shape) {
+    const KnnPlan p = knn_plan(cus, nq, nt, d, k, shape);
+    const KnnShape &sh = kShapes[p.shape];
+    const int T = (int)((nt + 31) / 32);
+    bool ok = p.nseg >= 1 && p.nseg <= FDR_MAX_SEG && p.segs.b[0] == 0 && p.qw == 32 * sh.nq * sh.nw &&
+              (int64_t)p.nqb * p.qw >= nq && p.nq_pad == p.nqb * p.qw;
+    for (int i = 0; i < p.nseg && ok; ++i) {
+        const int len = p.segs.b[i + 1] - p.segs.b[i];
+        ok = len > 0 && len % 32 == 0 && (sh.tps == 0 || len <= (1 << FDR_PREFILTER_MAX_IB));
+    }
+    ok = ok && p.segs.b[p.nseg] == T * 32;
+    for (int i = p.nseg; i <= FDR_MAX_SEG && ok; ++i) ok = p.segs.b[i] == T * 32;
+    ok = ok && p.total_bytes == p.bits_bytes + p.shared_bytes + p.partial_bytes &&
+         p.partial_bytes == (size_t)p.nseg * p.nq_pad * (size_t)k * 8;
+    if (!ok) printf("FAIL plan cus=%d nq=%lld nt=%lld d=%d k=%d shape=%d nseg=%d\n", cus, (long long)nq, (long long)nt, d, k, shape, p.nseg);
+    return ok ? 0 : 1;
+}
+
+static int cmd_plan() {
+    int bad = 0, n = 0;
+    const int64_t sizes[] = {20, 64, 8191, 8192, 8193, 100000, (1 << 19) - 1, 1 << 19, (1 << 19) + 1, 1000000,
+                             1250000, 2500000, 10000000, 20000000, ((int64_t)FDR_MAX_SEG << FDR_PREFILTER_MAX_IB)};
+    for (int cus : {256, 304, 64})
+        for (int64_t nt : sizes)
+            for (int d : {16, 128, 256, 500})
+                for (int k : {1, 20, 50, 64}) {
+                    if (nt < k) continue;
+                    const int dp = padded_dim(d);
+                    for (int64_t nq : {nt, (nt + 7) / 8, (int64_t)1}) {
+                        bad += check_plan(cus, nq, nt, d, k, -1);  // exact shapes
+                        ++n;
+                        const int kp = (k + prefilter_extra() + 1) & ~1;
+                        if (kp <= FDR_MAX_K && nt >= kp) {
+                            bad += check_plan(cus, nq, nt, d, kp, prefilter_shape(dp));
+                            bad += check_plan(cus, nq, nt, d, 1, range_shape(dp));
+                            n += 2;
+                        }
+                    }
+                }
+    // configs 4 / 5 of BASELINE.json: one rank's plan must fit FDR_MAX_SEG segments
+    const KnnPlan c4 = knn_plan(256, 1250000, 10000000, 128, 28, prefilter_shape(128));
+    const KnnPlan c5 = knn_plan(256, 2500000, 20000000, 256, 58, prefilter_shape(256));
+    printf("rc=%d plans=%d config4_nseg=%d config5_nseg=%d\n", bad ? 1 : 0, n, c4.nseg, c5.nseg);
+    return bad ? 1 : 0;
+}
+
+int main(int argc, char **argv) {
+    const std::string cmd = argc > 1 ? argv[1] : "";
+    if (cmd == "loader" && argc == 5) return cmd_loader(argv[2], atoll(argv[3]), atoi(argv[4]), false);
+    if (cmd == "loader-stale" && argc == 4) return cmd_loader(argv[2], atoll(argv[3]), 2, true);
+    if (cmd == "tables" && argc == 5) return cmd_tables((unsigned)atoi(argv[2]), atoll(argv[3]), atoi(argv[4]));
+    if (cmd == "plan") return cmd_plan();
+    if (cmd == "plan-print" && argc == 7) {  // host_san plan-print NQ NT D K SHAPE  (-1: the exact mode's choice)
+        const KnnPlan p = knn_plan(256, atoll(argv[2]), atoll(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+        printf("shape=%d nqb=%d nseg=%d tiles:", p.shape, p.nqb, p.nseg);
+        for (int i = 0; i < p.nseg; ++i) printf(" %d", (p.segs.b[i + 1] - p.segs.b[i]) / 32);
+        printf(" bytes=%zu\n", p.total_bytes);
+        return 0;
+    }
+    fprintf(stderr, "usage: host_san loader|loader-stale|tables|plan ...\n");
+    return 2;
+}

@@ -45,12 +45,22 @@ def test_no_gpu_fails_loudly(lib):
     assert "fdr_create" in str(e.value)
 
 
+def test_release_library_has_no_development_knobs():
+    """The shipped .so reads one environment variable (FDR_KNN_MODE, once, in fdr_create).  The timing /
+    wrong-result knobs of the development build (FDR_KNN_DEBUG, _EXTRA, _SLOTS, _OV, _NSEG, _SHAPE, _PAIR,
+    _RANGE, _DEDUP) must not exist in it: neither the names nor, hence, the getenv calls."""
+    build.build_library()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = set(re.findall(rb"FDR_[A-Z0-9_]*KNN[A-Z0-9_]*", blob))
+    assert names == {b"FDR_KNN_MODE"}, names
+
+
 def test_product_never_imports_oracle():
     """No file of the product may import, load or link the CPU oracle (comments may mention it)."""
     pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle)|libfedrann_oracle|orc_[a-z_]+\s*\(|oracle[/.]oracle",
                      re.M)
     for dirpath, _, files in os.walk(os.path.join(ROOT, "fedrann_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".inc", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(src), os.path.join(dirpath, f)

@@ -13,16 +13,17 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["exact", "prefilter", "exact+classes", "prefilter+classes"])
-def knn_mode(request, monkeypatch):
+def knn_mode(request, ctx):
     """Every test runs under both k-NN modes.  "prefilter" = fp16 MFMA candidate pass + certificate +
     exact fp32 re-rank (exact kernel for uncertified queries); its results must be the same bits.
     "+classes" forces the duplicate-row class layer (search unique rows, expand) at every size -- by
     default it only engages from 8192 target rows, which the large tests below cover."""
     mode, _, classes = request.param.partition("+")
-    monkeypatch.setenv("FDR_KNN_MODE", mode)
-    if classes:
-        monkeypatch.setenv("FDR_KNN_DEDUP", "2")
-    return request.param
+    ctx.set_knn_mode(mode)
+    ctx.set_dedup_mode("force" if classes else "auto")
+    yield request.param
+    ctx.set_knn_mode("auto")
+    ctx.set_dedup_mode("auto")
 
 
 def _skip_forced_classes(knn_mode):
@@ -53,6 +54,46 @@ def test_embed_matches_reference_golden(ctx, tag):
     ctx.projection_load(P[0], P[1], P[2], F, d)
     E = ctx.embed(ip, ix)
     assert np.array_equal(_bits(E), E_bits)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "mid"])
+def test_embed_of_compacted_csr_matches_reference_golden(ctx, tag):
+    """fdr_csr_compact drops the ids whose projection row is empty before the upload; E must stay the
+    reference's bits (the surviving ids keep their order, so the sequential fp32 sums are unchanged)."""
+    indptr, indices, P, F, d, E_bits = golden_embed_case(tag)
+    from fedrann_amd.feature_extraction import canonical_csr
+    ip, ix = canonical_csr(indptr, indices, F)
+    ctx.projection_load(P[0], P[1], P[2], F, d)
+    cip, cix = ctx.csr_compact(ip, ix)
+    nonempty = np.diff(P[0]) > 0
+    keep = nonempty[ix]
+    rows = np.repeat(np.arange(ip.size - 1), np.diff(ip))
+    assert np.array_equal(cix, ix[keep])
+    assert np.array_equal(np.diff(cip), np.bincount(rows[keep], minlength=ip.size - 1))
+    assert np.array_equal(_bits(ctx.embed(cip, cix)), E_bits)
+
+
+def test_compacted_csr_same_embedding_and_neighbours_on_synthetic(ctx):
+    s = synth(20_000, seed=11)
+    P = build_precompute_matrix(s["counts"], 128)
+    ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], 128)
+    cip, cix = ctx.csr_compact(s["indptr"], s["indices"], n_threads=3)
+    assert cix.size < 0.2 * s["indices"].size  # density 1/sqrt(F): most ids are dead
+    a = ctx.embed_knn(s["indptr"], s["indices"], 20, return_embedding=True)
+    b = ctx.embed_knn(cip, cix, 20, return_embedding=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+def test_development_knobs_do_not_reach_the_release_library(ctx, oracle, monkeypatch):
+    """FDR_KNN_DEBUG=1 used to skip the top-k slow path (timing experiments, wrong results); the release
+    build no longer reads it, nor any other knob (tests/test_abi.py checks the names are gone)."""
+    for name, val in (("FDR_KNN_DEBUG", "1"), ("FDR_KNN_EXTRA", "2"), ("FDR_KNN_NSEG", "7"), ("FDR_KNN_RANGE", "0")):
+        monkeypatch.setenv(name, val)
+    rng = np.random.default_rng(8)
+    E = rng.standard_normal((12_000, 96)).astype(np.float32)
+    E[rng.random(E.shape) < 0.9] = 0
+    _assert_knn_equal(ctx.knn(E, 20), oracle.knn(E, 20))
 
 
 @pytest.mark.parametrize("R,d,m", [(3000, 128, 200), (1500, 64, 50), (800, 200, 120), (500, 256, 400),
