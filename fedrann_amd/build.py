@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "fedrann_hip.hip")
 OUT = os.path.join(HERE, "libfedrann_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-result", "-pthread"]
+         "-Wall", "-Wno-unused-result", "-Wno-inline-asm", "-pthread"]
 
 
 def hipcc_path():

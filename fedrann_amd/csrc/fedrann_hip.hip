@@ -174,6 +174,11 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restr
 #include "csr_compact.inc"        // dead-feature filter (plain C++)
 #include "knn_exact.inc"      // K3 / K4: fp32 MFMA tile kernel with LDS top-k lists, merge
 #include "knn_prefilter.inc"  // P1 / P2: fp16 MFMA candidate pass, merges, certificate + re-rank, range pass
+#ifdef FDR_DEV
+#include "knn_prefilter2.inc" // P1, second shape (measured slower, development builds only): 256 queries / workgroup
+#else
+#define PF2_PAD_ROWS 0
+#endif
 #include "dedup_classes.inc"  // duplicate-row classes: hash, tables, gathers, expansion
 
 // ------------------------------------------------------------------------------------------
@@ -494,13 +499,13 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.chunk = (int)std::min<int64_t>(nq, 16384);
     const size_t exact_all = knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
     const int dp = fdr_padded_dim(d);
-    const size_t pre = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp)).total_bytes;
+    const size_t pre = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp)).total_bytes;
     // any exact plan for <= chunk queries: bits + bound words + at most FDR_MAX_SEG segments of lists
     const size_t chunk_bound = align256((size_t)((nt + 31) / 32) * 4) + align256((size_t)(L.chunk + 128) * 4) +
                                (size_t)FDR_MAX_SEG * (L.chunk + 128) * (size_t)k * 8;
     L.knn_bytes = align256(std::max(exact_all, std::max(pre, chunk_bound)));
     size_t o = L.knn_bytes;
-    L.off_ht = o;       o += align256((size_t)nt * dp * 2);
+    L.off_ht = o;       o += align256((size_t)(nt + PF2_PAD_ROWS) * dp * 2);  // (+ readable rows behind the copy)
     L.off_hq = o;       o += align256((size_t)nq * dp * 2);
     L.off_cand = o;     o += align256((size_t)nq * L.kp * 8);
     L.off_counter = o;  o += 1024;  // [0] exact list, [1] all-zero queries, [2] range list; zero answer at +256 / +512
@@ -613,8 +618,9 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     const int kp = L.kp;
 
     const int dp = fdr_padded_dim(d);
-    const KnnPlan p = knn_plan(ctx->num_cus, nq, nt, d, kp, prefilter_shape(dp));
-    const KnnShape &sh = kShapes[prefilter_shape(dp)];
+    const int pshape = prefilter_shape(dp, kp);
+    const KnnPlan p = knn_plan(ctx->num_cus, nq, nt, d, kp, pshape);
+    const KnnShape &sh = kShapes[pshape];
     unsigned *d_bits = reinterpret_cast<unsigned *>(ws);
     unsigned *d_shared = reinterpret_cast<unsigned *>(ws + p.bits_bytes);
     u64 *d_partial = reinterpret_cast<u64 *>(ws + p.bits_bytes + p.shared_bytes);
@@ -649,10 +655,16 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
         if (kp <= 32) FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 16);                                     \
         else FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 32);                                              \
     } while (0)
-    if (prefilter_shape(dp) == 8) {
-        if (kp <= 32) FDR_LAUNCH_PRE2(128, 2, 4, 2, 2, 16);
-        else FDR_LAUNCH_PRE2(128, 2, 4, 2, 2, 32);
-    } else if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_PAIR", 1) != 0) {
+#ifdef FDR_DEV
+    if (pshape == FDR_SHAPE_PREFILTER2) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter2_kernel<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((knn_prefilter2_kernel<16>), dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(256), lds, st,
+                           d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, d_shared,
+                           ib FDR_DBG_ARG(pdbg));
+    } else
+#endif
+    if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_PAIR", 1) != 0) {
         // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
         // <= 128 VGPRs.  FDR_KNN_PAIR=0: development knob, one chain)
         hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)p.nqb, (unsigned)p.nseg),
