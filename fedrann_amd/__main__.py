@@ -1,21 +1,27 @@
-"""`python -m fedrann_amd` -- the fedrann command line for the GPU hot path.
+"""`python -m fedrann_amd` -- the fedrann command line on the GPU hot path.
 
 Keeps the reference's flags and defaults (fedrann/__main__.py:69-171) and its stage sequence
-(run_fedrann_pipeline :302-391) for stages 2-4: projection matrix -> embeddings -> k-NN ->
-overlaps.tsv.  Stage 1 (k-mer counting / sampling / kmer_searcher, count_kmers.py) is outside this
-build's scope; its products are accepted as inputs instead:
+(run_fedrann_pipeline :302-391): k-mer counting / sampling / search (stage 1, on the GPU too) ->
+projection matrix -> embeddings -> k-NN -> overlaps.tsv.  Entry points:
 
+    -i reads.fa[.gz]                              the whole pipeline, like the reference
+    -i reads.fa --kmer-library fwd_kmer_library.fasta          stage 1b on (search only)
     --kmer-searcher-output out/temp/kmer_searcher/output.bin --kmer-library out/temp/fwd_kmer_library.fasta
         (what the reference leaves behind with --keep-intermediates), or
     --feature-matrix feature_matrix.npz --kmer-counts counts.npy [--read-names names.txt]
         (scipy.sparse.save_npz binary CSR of the rows to search; see feature_extraction.py).
 
-`-i/--input` with a FASTA/FASTQ file is accepted only to explain that.
+--devices 0,1,...: the rows are sharded over several GPUs of the node.  The parent process starts one
+child per GPU BEFORE it touches a GPU itself; every child embeds its row block, the blocks are
+all-gathered (RCCL), every child searches its rows against all rows and writes its part of overlaps.tsv;
+the parent concatenates the parts in rank order (byte-identical to the single-GPU file).
 """
 import argparse
 import logging
 import os
 from os.path import abspath, join
+import subprocess
+import sys
 from shutil import copyfileobj, rmtree
 from typing import List
 
@@ -82,6 +88,12 @@ def build_parser():
     g.add_argument("--read-names", type=str, default=None,
                    help="With --feature-matrix: text file, one 'name<TAB>strand' (or just name) per row.")
     g.add_argument("--device", type=int, default=None, help="GPU ordinal (default $LOCAL_RANK or 0).")
+    g.add_argument("--devices", type=str, default=None,
+                   help="Comma-separated GPU ordinals: shard the rows over these GPUs (one process each).")
+    g.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                   help="With --devices: nccl (= RCCL over xGMI; one GPU per process) or gloo (processes may "
+                        "share a GPU: one-GPU rehearsal of the sharded path).")
+    g.add_argument("--rank-worker", action="store_true", default=False, help=argparse.SUPPRESS)
     return p
 
 
@@ -129,10 +141,16 @@ def get_output_dataframe(neighbor_matrix, neighbor_distances, read_names: List[s
     return df
 
 
-def write_overlaps(path, neighbor_matrix, distances, read_names, strands):
-    df = get_output_dataframe(neighbor_matrix, distances, read_names, strands)
-    df.to_csv(path, sep="\t", index=False)  # __main__.py:385
-    return df.shape[0]
+def write_overlaps(path, neighbor_matrix, distances, read_names, strands, row0=0, header=True):
+    """overlaps.tsv through the native writer (fdr_overlaps_write): the bytes get_output_dataframe(...)
+    .to_csv(path, sep="\\t", index=False) produces (__main__.py:261-300, :385), without the DataFrame.
+    neighbor_matrix / distances may be the rows row0.. of the graph (a rank's block); read_names / strands
+    describe all rows.  Returns the number of data lines."""
+    from . import _lib
+    name_off, names = _lib.pack_names(read_names)
+    return _lib.overlaps_write(path, np.asarray(neighbor_matrix), np.asarray(distances), name_off, names,
+                               np.asarray(strands, dtype=np.uint8), row0=row0, header=header,
+                               n_threads=global_variables.threads if global_variables.threads > 1 else 0)
 
 
 def _load_counts(path):
@@ -156,41 +174,68 @@ def _load_names(path, nrows):
     return names, strands
 
 
-def run_fedrann_pipeline(*, output_dir, embedding_dimension, nndescent_n_trees,
-                         nndescent_n_neighbors, save_feature_matrix, keep_intermediates, chunk_size,
-                         kmer_searcher_output=None, kmer_library=None, feature_matrix=None,
-                         kmer_counts=None, read_names_path=None):
-    """Stages 2-4 of the reference pipeline (__main__.py:329-391)."""
+def check_limits(embedding_dimension, nndescent_n_neighbors):
+    """The k-NN kernels' limits, checked before any work is done (the reference accepts any value)."""
+    from . import _lib
+    if not 1 <= embedding_dimension <= _lib.FDR_MAX_DIM:
+        raise SystemExit("-n/--embedding-dimension must be in 1..%d for the GPU k-NN kernels (got %d)"
+                         % (_lib.FDR_MAX_DIM, embedding_dimension))
+    if not 1 <= nndescent_n_neighbors <= _lib.FDR_MAX_K:
+        raise SystemExit("--nndescent-n-neighbors must be in 1..%d for the GPU k-NN kernels (got %d)"
+                         % (_lib.FDR_MAX_K, nndescent_n_neighbors))
+
+
+def load_inputs(*, output_dir, embedding_dimension, save_feature_matrix, kmer_searcher_output=None,
+                kmer_library=None, feature_matrix=None, kmer_counts=None, read_names_path=None, save=True):
+    """Stages 2-3a of the reference pipeline on the host (__main__.py:329-345): the projection matrix and
+    the read x feature CSR.  Returns (indptr, indices, n_features, P, read_names, strands)."""
     if kmer_searcher_output:
-        logger.info("--- 1. (skipped) using kmer_searcher output %s ---", kmer_searcher_output)
-        # n_features = 2 * |forward library| (count_kmers.py:148)
         from .precompute import read_kmer_counts
-        n_features = 2 * int(read_kmer_counts(kmer_library).size)
+        n_features = 2 * int(read_kmer_counts(kmer_library).size)  # (count_kmers.py:148)
         logger.info("--- 2. Generate dimension reduction and IDF matrix ---")
-        P, n_features = get_precompute_matrix(n_components=embedding_dimension,
-                                              counter_file=kmer_library, n_features=n_features)
+        P, n_features = get_precompute_matrix(n_components=embedding_dimension, counter_file=kmer_library,
+                                              n_features=n_features)
         logger.info("--- 3. Generate feature matrix ---")
         indptr, indices, read_names, strands = build_feature_csr(kmer_searcher_output, n_features)
-        if save_feature_matrix:
-            save_feature_matrix_npz(join(output_dir, "feature_matrix.npz"), indptr, indices, n_features)
-        embedding_matrix = embed_csr(indptr, indices, P)
     else:
-        logger.info("--- 1. (skipped) using feature matrix %s ---", feature_matrix)
         indptr, indices, n_features = load_feature_matrix_npz(feature_matrix)
         counts = _load_counts(kmer_counts)
         logger.info("--- 2. Generate dimension reduction and IDF matrix ---")
         P = build_precompute_matrix(counts, embedding_dimension, n_features=n_features)
         logger.info("--- 3. Generate feature matrix ---")
         read_names, strands = _load_names(read_names_path, indptr.size - 1)
-        if save_feature_matrix:
-            save_feature_matrix_npz(join(output_dir, "feature_matrix.npz"), indptr, indices, n_features)
-        embedding_matrix = embed_csr(indptr, indices, P)
+    if save_feature_matrix and save:
+        save_feature_matrix_npz(join(output_dir, "feature_matrix.npz"), indptr, indices, n_features)
+    return indptr, indices, n_features, P, read_names, strands
 
+
+def run_fedrann_pipeline(*, output_dir, embedding_dimension, nndescent_n_trees,
+                         nndescent_n_neighbors, save_feature_matrix, keep_intermediates, chunk_size,
+                         kmer_searcher_output=None, kmer_library=None, feature_matrix=None,
+                         kmer_counts=None, read_names_path=None):
+    """Stages 2-4 of the reference pipeline (__main__.py:329-391) on one GPU.  The embeddings never leave
+    HBM between the projection and the search (fdr_embed_knn), and only the features P has entries for
+    cross PCIe (fdr_csr_compact; the saved feature_matrix.npz is the full matrix)."""
+    from . import _lib
+    from .feature_extraction import _projection_csr
+    if kmer_searcher_output:
+        logger.info("--- 1. (skipped) using kmer_searcher output %s ---", kmer_searcher_output)
+    else:
+        logger.info("--- 1. (skipped) using feature matrix %s ---", feature_matrix)
+    indptr, indices, n_features, P, read_names, strands = load_inputs(
+        output_dir=output_dir, embedding_dimension=embedding_dimension, save_feature_matrix=save_feature_matrix,
+        kmer_searcher_output=kmer_searcher_output, kmer_library=kmer_library, feature_matrix=feature_matrix,
+        kmer_counts=kmer_counts, read_names_path=read_names_path)
+    ctx = _lib.default_context()
+    Pc = _projection_csr(P)
+    ctx.projection_load(Pc.indptr, Pc.indices, Pc.data, n_features, embedding_dimension)
+    cip, cix = ctx.csr_compact(indptr, indices)
+    logger.debug("embedding %d rows: %d of %d feature ids have an entry in P", indptr.size - 1, cix.size, indices.size)
+    del indptr, indices
     logger.info("--- 4. Nearest Neighbors Search ---")
-    neighbor_matrix, distances = get_neighbors_ava(embedding_matrix,
-                                                   nndescent_n_trees=nndescent_n_trees,
-                                                   nndescent_n_neighbors=nndescent_n_neighbors)
-    del embedding_matrix
+    logger.info("Using exact GPU k-NN in place of NNDescent (n_trees = %s, leaf_size = %s are inert)",
+                nndescent_n_trees, 200)
+    neighbor_matrix, distances = ctx.embed_knn(cip, cix, nndescent_n_neighbors)
     nbr_output_file = join(output_dir, "overlaps.tsv")
     logger.debug("Saving overlap table to %s", nbr_output_file)
     rows = write_overlaps(nbr_output_file, neighbor_matrix, distances, read_names, strands)
@@ -198,6 +243,91 @@ def run_fedrann_pipeline(*, output_dir, embedding_dimension, nndescent_n_trees,
     if not keep_intermediates and global_variables.temp_dir and os.path.isdir(global_variables.temp_dir):
         logger.debug("Removing intermediate files")
         rmtree(global_variables.temp_dir)
+    logger.info("Pipeline completed.")
+
+
+def run_rank_worker(args, output_dir, temp_dir):
+    """One rank of `--devices`: RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / FEDRANN_DEVICE come from
+    the parent.  Rank 0 runs stage 1 if reads were given; every rank then embeds its row block, the
+    normalised blocks are all-gathered, every rank searches its rows against all rows
+    (distributed.ShardedPipeline) and writes temp/overlaps.rank<r>.tsv."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    from .distributed import HipEngine, ShardedPipeline, local_csr
+    from .feature_extraction import _projection_csr
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    device = torch.device("cuda", int(os.environ["FEDRANN_DEVICE"]))
+    torch.cuda.set_device(device)
+    if args.dist_backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    have_ks = bool(args.kmer_searcher_output)
+    if args.input and not have_ks and not args.feature_matrix:
+        ks_path = join(temp_dir, "kmer_searcher", "output.bin")
+        if rank == 0:
+            if args.kmer_library:
+                logger.info("--- 1b. k-mer search on the GPU ---")
+                _gpu_kmer_search(args.input, args.kmer_library, args.kmer_size, temp_dir)
+            else:
+                from .count_kmers import run_kmer_searcher
+                logger.info("--- 1. Counter kmers (GPU) ---")
+                run_kmer_searcher(input_path=args.input, k=args.kmer_size, sample_fraction=args.kmer_sample_fraction,
+                                  min_multiplicity=args.kmer_min_multiplicity)
+        dist.barrier()
+        args.kmer_searcher_output = ks_path
+        if not args.kmer_library:
+            args.kmer_library = join(temp_dir, "fwd_kmer_library.fasta")
+    indptr, indices, n_features, P, read_names, strands = load_inputs(
+        output_dir=output_dir, embedding_dimension=args.embedding_dimension,
+        save_feature_matrix=args.save_feature_matrix, kmer_searcher_output=args.kmer_searcher_output,
+        kmer_library=args.kmer_library, feature_matrix=args.feature_matrix, kmer_counts=args.kmer_counts,
+        read_names_path=args.read_names, save=rank == 0)
+    n, k = indptr.size - 1, args.nndescent_n_neighbors
+    ctx = _lib.Context(device.index)
+    Pc = _projection_csr(P)
+    ctx.projection_load(Pc.indptr, Pc.indices, Pc.data, n_features, args.embedding_dimension)
+    pipe = ShardedPipeline(HipEngine(ctx, device), n, args.embedding_dimension, k, rank=rank, world_size=world,
+                           device=device)
+    ip, ix = local_csr(indptr, indices, pipe.lo, pipe.hi)
+    ip, ix = ctx.csr_compact(ip, ix)
+    del indptr, indices
+    if rank == 0:
+        logger.info("--- 4. Nearest Neighbors Search (%d rows over %d GPUs) ---", n, world)
+    idx, dst, _ = pipe.step(torch.from_numpy(ip).to(device), torch.from_numpy(ix).to(device))
+    torch.cuda.synchronize(device)
+    part = join(temp_dir, "overlaps.rank%d.tsv" % rank)
+    rows = write_overlaps(part, idx.cpu().numpy(), dst.cpu().numpy(), read_names, strands, row0=pipe.lo,
+                          header=rank == 0)
+    logger.debug("rank %d: rows [%d, %d), %d overlap rows", rank, pipe.lo, pipe.hi, rows)
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+def launch_rank_workers(argv, devices, output_dir, temp_dir, keep_intermediates):
+    """The parent of `--devices`: no GPU call here (a process that has initialised the GPU must not start
+    others on this pool, and the children own the devices).  Children = this module with --rank-worker."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank, dev in enumerate(devices):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FEDRANN_DEVICE=str(dev))
+        procs.append(subprocess.Popen([sys.executable, "-m", "fedrann_amd"] + list(argv) + ["--rank-worker"], env=env))
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        raise SystemExit("rank worker(s) failed: exit codes %s" % codes)
+    out = join(output_dir, "overlaps.tsv")
+    with open(out, "wb") as dst:
+        for rank in range(len(devices)):
+            with open(join(temp_dir, "overlaps.rank%d.tsv" % rank), "rb") as src:
+                copyfileobj(src, dst, 1 << 24)
+    if not keep_intermediates and os.path.isdir(temp_dir):
+        rmtree(temp_dir)
     logger.info("Pipeline completed.")
 
 
@@ -219,16 +349,20 @@ def _gpu_kmer_search(reads_path, fwd_library, k, temp_dir):
             copyfileobj(src, dst, 1 << 24)
         reads_path = plain
     out_dir = join(temp_dir, "kmer_searcher")
-    ids, indptr, indices, n_lib = kmer_searcher([fwd_library, rev_path], reads_path, out_dir, k)
+    ids, indptr, indices, n_lib = kmer_searcher([fwd_library, rev_path], reads_path, out_dir, k,
+                                                fastq_ids_as_fasta=True)  # (the reference runs seqkit fq2fa first)
     logger.debug("k-mer search: %d reads, %d library k-mers, %d hits", len(ids), n_lib, indices.size)
     return join(out_dir, "output.bin")
 
 
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_command_line_arguments(argv)
     global_variables.threads = args.threads
     global_variables.seed = args.seed
-    if args.device is not None:
+    check_limits(args.embedding_dimension, args.nndescent_n_neighbors)  # before any work (the library would
+    # only refuse them after stages 1-3)
+    if args.device is not None and not args.rank_worker:
         os.environ["FEDRANN_DEVICE"] = str(args.device)
     output_dir = abspath(args.output_dir)
     os.makedirs(output_dir, exist_ok=True)
@@ -237,10 +371,26 @@ def main(argv=None):
     temp_dir = join(output_dir, "temp")
     os.makedirs(temp_dir, exist_ok=True)
     global_variables.temp_dir = temp_dir
-    logger.info("FEDRANN (MI355X hot path) version: %s", __version__)
-    logger.debug("Parameters: %s", args)
     have_ks = bool(args.kmer_searcher_output)
     have_fm = bool(args.feature_matrix)
+    if sum((bool(args.input), have_ks, have_fm)) != 1:
+        raise SystemExit(
+            "give exactly one of -i reads, -i reads + --kmer-library, --kmer-searcher-output + --kmer-library, "
+            "or --feature-matrix + --kmer-counts")
+    if have_ks and not args.kmer_library:
+        raise SystemExit("--kmer-searcher-output needs --kmer-library")
+    if have_fm and not args.kmer_counts:
+        raise SystemExit("--feature-matrix needs --kmer-counts")
+    if args.rank_worker:
+        return run_rank_worker(args, output_dir, temp_dir)
+    logger.info("FEDRANN (MI355X hot path) version: %s", __version__)
+    logger.debug("Parameters: %s", args)
+    if args.devices:
+        devices = [int(x) for x in args.devices.split(",") if x.strip() != ""]
+        if len(devices) > 1:
+            return launch_rank_workers(argv, devices, output_dir, temp_dir, args.keep_intermediates)
+        if devices:
+            os.environ["FEDRANN_DEVICE"] = str(devices[0])
     if args.input and args.kmer_library and not have_ks and not have_fm:
         # stage 1b on the GPU: reads x sampled k-mer library -> output.bin (count_kmers.py:119-139 with the
         # reverse library made here instead of by seqkit, the search by fdr_kmer_search instead of kmer_searcher)
@@ -258,14 +408,6 @@ def main(argv=None):
         logger.debug("kmer_searcher n_features: %d, reads: %d", n_features, read_count)
         args.kmer_library = join(temp_dir, "fwd_kmer_library.fasta")
         have_ks = True
-    if have_ks == have_fm:
-        raise SystemExit(
-            "give exactly one of -i reads, -i reads + --kmer-library, --kmer-searcher-output + --kmer-library, "
-            "or --feature-matrix + --kmer-counts")
-    if have_ks and not args.kmer_library:
-        raise SystemExit("--kmer-searcher-output needs --kmer-library")
-    if have_fm and not args.kmer_counts:
-        raise SystemExit("--feature-matrix needs --kmer-counts")
     run_fedrann_pipeline(
         output_dir=output_dir, embedding_dimension=args.embedding_dimension,
         nndescent_n_trees=args.nndescent_n_trees, nndescent_n_neighbors=args.nndescent_n_neighbors,

@@ -18,6 +18,7 @@ SYMBOLS = (
     "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_set_dedup_mode", "fdr_last_unique", "fdr_kmer_output_scan",
     "fdr_kmer_output_load", "fdr_kmer_search", "fdr_kmer_search_indices", "fdr_kmer_count",
     "fdr_kmer_count_fetch", "fdr_csr_compact", "fdr_host_register", "fdr_host_unregister",
+    "fdr_overlaps_write",
 )
 FDR_MAX_K = 64
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
@@ -89,6 +90,7 @@ def load_library():
     L.fdr_csr_compact.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32]
     L.fdr_host_register.argtypes = [vp, vp, sz]
     L.fdr_host_unregister.argtypes = [vp, vp]
+    L.fdr_overlaps_write.argtypes = [ctypes.c_char_p, i32, i32, i64, i64, i64, i32, vp, vp, vp, vp, vp, i32, p64]
     L.fdr_kmer_search.argtypes = [vp, vp, vp, i64, vp, i64, i32, vp, p64]
     L.fdr_kmer_search_indices.argtypes = [vp, vp]
     L.fdr_kmer_count.argtypes = [vp, vp, vp, i64, i32, i64, p64]
@@ -133,6 +135,39 @@ def kmer_output_load(path, n_features, n_threads=0):
     if rc != 0:
         raise FedrannHipError("fdr_kmer_output_load failed (%d): %s" % (rc, L.fdr_last_error().decode()))
     return indptr, indices, name_off, names
+
+
+def pack_names(read_names):
+    """list of str / bytes -> (name_off int64 [n + 1], names uint8 buffer) for fdr_overlaps_write."""
+    enc = [n if isinstance(n, bytes) else str(n).encode("utf-8") for n in read_names]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    if enc:
+        np.cumsum([len(b) for b in enc], out=off[1:])
+    return off, np.frombuffer(b"".join(enc), dtype=np.uint8)
+
+
+def overlaps_write(path, idx, dist, name_off, names, strands, row0=0, append=False, header=True, n_threads=0):
+    """overlaps.tsv rows of neighbour-graph rows row0 .. row0 + idx.shape[0] (host only, no GPU); returns the
+    number of data lines.  See fdr_overlaps_write."""
+    L = load_library()
+    idx = _as(idx, np.int32, "idx")
+    dist = _as(dist, np.float32, "dist")
+    if idx.ndim != 2 or dist.shape != idx.shape:
+        raise ValueError("idx and dist must be [rows, k] arrays of the same shape")
+    name_off = _as(name_off, np.int64, "name_off")
+    names = np.ascontiguousarray(names, dtype=np.uint8)
+    strands = np.ascontiguousarray(strands, dtype=np.uint8)
+    n_total = name_off.size - 1
+    if strands.size != n_total:
+        raise ValueError("strands must have one entry per row")
+    lines = ctypes.c_int64()
+    rc = L.fdr_overlaps_write(os.fsencode(path), 1 if append else 0, 1 if header else 0, n_total, int(row0),
+                              idx.shape[0], idx.shape[1], _ptr(idx), _ptr(dist), _ptr(name_off),
+                              names.ctypes.data if names.size else None, _ptr(strands), int(n_threads),
+                              ctypes.byref(lines))
+    if rc != 0:
+        raise FedrannHipError("fdr_overlaps_write failed (%d): %s" % (rc, L.fdr_last_error().decode()))
+    return int(lines.value)
 
 
 class Context:

@@ -75,7 +75,7 @@ def run_kmer_searcher(input_path, k, sample_fraction, min_multiplicity=2, contex
         input_path = plain
     if not input_path.endswith((".fasta", ".fa", ".fastq", ".fq")):
         raise ValueError("Unsupported file format. Please provide a FASTA or FASTQ file.")  # count_kmers.py:72-75
-    ids, seqs, off = read_sequences(input_path)
+    ids, seqs, off = read_sequences(input_path, fastq_ids_as_fasta=True)  # (the reference runs seqkit fq2fa first)
     codes, counts = count_canonical_kmers(seqs, off, k, min_multiplicity, context=context)
     keep = sample_kmers(codes.size, sample_fraction, global_variables.seed)
     fwd = join(tmp, "fwd_kmer_library.fasta")
@@ -87,5 +87,5 @@ def run_kmer_searcher(input_path, k, sample_fraction, min_multiplicity=2, contex
         for line in f:
             g.write(line if line.startswith(b">") else line.rstrip(b"\n").translate(comp)[::-1] + b"\n")
     out_dir = join(tmp, "kmer_searcher")
-    ids2, _, _, _ = kmer_searcher([fwd, rev], input_path, out_dir, k, context=context)
+    ids2, _, _, _ = kmer_searcher([fwd, rev], input_path, out_dir, k, context=context, fastq_ids_as_fasta=True)
     return join(out_dir, "output.bin"), kmer_count * 2, len(ids2)

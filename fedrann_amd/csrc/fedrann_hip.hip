@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <limits>
+#include <string>
 #include <cstdint>
 #include <cstdio>
 #include <cmath>
@@ -634,7 +636,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     hipLaunchKernelGGL(pack_zero_bits_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st,
                        d_tzero, (int)nt, d_bits, d_shared, p.nq_pad);
     HIP_TRY(hipGetLastError());
-    const size_t lds = knn_lds_bytes(sh, kp);
+    const size_t lds = knn_lds_bytes(sh, kp) + (size_t)dev_env_int("FDR_KNN_LDSPAD", 0);  // (development: fewer workgroups per CU)
     int max_seg = 1;
     for (int i = 0; i < p.nseg; ++i) max_seg = std::max(max_seg, p.segs.b[i + 1] - p.segs.b[i]);
     const int ib = prefilter_index_bits(max_seg);
@@ -1086,3 +1088,4 @@ FDR_EXPORT int fdr_embed_knn(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indp
 
 #include "kmer_search.inc"
 #include "kmer_output_loader.inc"
+#include "overlaps_writer.inc"

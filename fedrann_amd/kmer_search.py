@@ -58,9 +58,22 @@ def load_kmer_library(texts, k):
     return np.ascontiguousarray(codes[first])
 
 
-def read_sequences(path):
+def fasta_id(header):
+    """The part of a header line kmer_searcher keeps for a FASTA record: up to the first space or tab."""
+    cut = len(header)
+    for sep in (b" ", b"\t"):
+        p = header.find(sep)
+        if 0 <= p < cut:
+            cut = p
+    return header[:cut]
+
+
+def read_sequences(path, fastq_ids_as_fasta=False):
     """FASTA / FASTQ -> (ids list of bytes, seqs uint8 [total], seq_off int64 [R+1]) exactly as
-    kmer_searcher.cpp:153-200 reads them: FASTQ iff the first line starts with '@'.  FASTA: id = header up
+    kmer_searcher.cpp:153-200 reads them: FASTQ iff the first line starts with '@'.
+    fastq_ids_as_fasta: the PIPELINE never shows kmer_searcher a FASTQ file -- count_kmers.py:76-79 converts
+    it with `seqkit fq2fa` first, so a read's name is its header up to the first space or tab (the FASTA
+    rule) there, and a record with an empty name is dropped; the stand-alone tool keeps the whole line.  FASTA: id = header up
     to the first space or tab; the sequence is every following line with only the '\\n' removed (a '\\r'
     stays and is an invalid character); empty lines are skipped; a record whose id is empty, and anything
     before the first header, is dropped.  FASTQ: id = the whole header line after '@', sequence = the
@@ -81,8 +94,12 @@ def read_sequences(path):
         ids, pieces, i, n = [], [], 0, starts.size
         while i < n:
             if lens[i] > 0 and first[i] == ord("@"):
-                ids.append(raw[starts[i] + 1:ends[i]])
-                pieces.append(raw[starts[i + 1]:ends[i + 1]] if i + 1 < n else b"")
+                name = raw[starts[i] + 1:ends[i]]
+                if fastq_ids_as_fasta:
+                    name = fasta_id(name)
+                if not (fastq_ids_as_fasta and len(name) == 0):
+                    ids.append(name)
+                    pieces.append(raw[starts[i + 1]:ends[i + 1]] if i + 1 < n else b"")
                 i += 4
             else:
                 i += 1
@@ -96,13 +113,7 @@ def read_sequences(path):
     heads = np.flatnonzero(is_head)
     ids = []
     for h in heads.tolist():
-        line = raw[starts[h] + 1:ends[h]]
-        cut = len(line)
-        for sep in (b" ", b"\t"):
-            p = line.find(sep)
-            if 0 <= p < cut:
-                cut = p
-        ids.append(line[:cut])
+        ids.append(fasta_id(raw[starts[h] + 1:ends[h]]))
     has_id = np.array([len(x) > 0 for x in ids], dtype=bool)
     keep_line = nonempty & ~is_head & (rec_of_line >= 0)
     if has_id.size:
@@ -153,12 +164,13 @@ def write_kmer_frequency_bin(path, indices, n_lib):
     out.tofile(path)
 
 
-def kmer_searcher(kmer_lib, input_reads, output_dir, k, threads=None, context=None):
+def kmer_searcher(kmer_lib, input_reads, output_dir, k, threads=None, context=None, fastq_ids_as_fasta=False):
     """Drop-in for the command line `kmer_searcher <kmer_lib> <input> <output_dir> <k> <threads>`
     (kmer_searcher.cpp:232-375).  `kmer_lib`: a path, a list of paths (read in order, like
     `cat fwd rev | grep -v '^>'`; '>' header tokens are not k long and drop out by themselves unless a
     count happens to have k digits -- so, as in the reference's pipeline, header lines are removed first).
-    Writes output_dir/output.bin and output_dir/kmer_frequency.bin; returns (ids, indptr, indices, n_lib)."""
+    Writes output_dir/output.bin and output_dir/kmer_frequency.bin; returns (ids, indptr, indices, n_lib).
+    fastq_ids_as_fasta: see read_sequences (the pipeline's callers set it)."""
     paths = [kmer_lib] if isinstance(kmer_lib, (str, bytes, os.PathLike)) else list(kmer_lib)
     texts = []
     for p in paths:
@@ -166,7 +178,7 @@ def kmer_searcher(kmer_lib, input_reads, output_dir, k, threads=None, context=No
             t = f.read()
         texts.append(b"\n".join(l for l in t.split(b"\n") if not l.startswith(b">")) + b"\n")
     codes = load_kmer_library(texts, k)
-    ids, seqs, off = read_sequences(input_reads)
+    ids, seqs, off = read_sequences(input_reads, fastq_ids_as_fasta=fastq_ids_as_fasta)
     indptr, indices = search(seqs, off, codes, k, context=context)
     os.makedirs(output_dir, exist_ok=True)
     write_output_bin(os.path.join(output_dir, "output.bin"), ids, indptr, indices)

@@ -207,6 +207,20 @@ int fdr_kmer_output_scan(const char *path, int64_t *n_records, int64_t *nnz, int
 int fdr_kmer_output_load(const char *path, int64_t n_features, int32_t n_threads, int64_t n_records, int64_t nnz,
                          int64_t name_bytes, int64_t *indptr, int32_t *indices, int64_t *name_off, char *names);
 
+/* ---- overlaps.tsv writer (host only: no context, no GPU) ---------------------------------------------
+ * Replaces get_output_dataframe + DataFrame.to_csv(sep="\t", index=False) (fedrann/__main__.py:261-300,
+ * :385): for every row q = row0 + r (r < n_rows) and column c with target t = idx[r][c], in that order,
+ * unless t == q:   name[q] \t "+-"[strand[q]] \t name[t] \t "+-"[strand[t]] \t c \t dist[r][c] \n
+ * byte for byte what pandas writes for the reference's DataFrame (float32 distances in their shortest
+ * round-trip form, numpy layout; a negative t aliases from the end like Python indexing).  idx / dist
+ * [n_rows, k] are the rows row0 .. row0 + n_rows of the neighbour graph (a rank's block of a row-sharded
+ * run); names / name_off / strands describe all n_total rows.  append: open the file for appending;
+ * write_header: the column-name line first.  n_threads <= 0: all hardware threads.  *lines_out (may be
+ * NULL) = data lines written. */
+int fdr_overlaps_write(const char *path, int32_t append, int32_t write_header, int64_t n_total, int64_t row0,
+                       int64_t n_rows, int32_t k, const int32_t *idx, const float *dist, const int64_t *name_off,
+                       const char *names, const uint8_t *strands, int32_t n_threads, int64_t *lines_out);
+
 #ifdef __cplusplus
 }
 #endif

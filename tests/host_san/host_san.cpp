@@ -1,12 +1,14 @@
 // Host-only build of the library's plain-C++ parts under AddressSanitizer + UBSan (never the GPU build):
 //   kmer_output_loader.inc (output.bin -> CSR), projection_tables.inc (the embed kernel's lookup tables),
-//   csr_compact.inc (dead-feature filter), knn_plan.inc (launch planner).
+//   csr_compact.inc (dead-feature filter), knn_plan.inc (launch planner), overlaps_writer.inc (overlaps.tsv).
 // tests/test_host_san.py builds this with g++ -fsanitize=address,undefined and drives it; each command
 // prints a result line that the test compares with what libfedrann_hip.so returns for the same input.
 //
 //   host_san loader PATH N_FEATURES THREADS       -> "rc=<code> R=.. nnz=.. sums=<4 weighted sums>" | "rc=<code> err=<msg>"
 //   host_san loader-stale PATH N_FEATURES         -> load with capacities that no longer match: must fail cleanly
 //   host_san tables SEED N_FEATURES D             -> builds tables for a random very-sparse P, checks them, compacts a CSR
+//   host_san floats N  (hex float32 words on stdin) -> the writer's text of each
+//   host_san overlaps OUT THREADS                 -> writes a random neighbour graph (whole, and as two appended blocks)
 //   host_san plan-print NQ NT D K SHAPE           -> one plan (devtools)
 //   host_san plan                                 -> sweeps the planner over edge sizes, checks invariants
 #include <algorithm>
@@ -17,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <random>
 #include <string>
 #include <thread>
@@ -29,6 +32,7 @@
 #include "../../fedrann_amd/csrc/projection_tables.inc"
 #include "../../fedrann_amd/csrc/csr_compact.inc"
 #include "../../fedrann_amd/csrc/kmer_output_loader.inc"
+#include "../../fedrann_amd/csrc/overlaps_writer.inc"
 
 template <typename T>
 static uint64_t wsum(const std::vector<T> &v) {  // sum of (i + 1) * v[i] mod 2^64 (numpy can restate it)
@@ -199,6 +203,56 @@ int main(int argc, char **argv) {
     if (cmd == "loader-stale" && argc == 4) return cmd_loader(argv[2], atoll(argv[3]), 2, true);
     if (cmd == "tables" && argc == 5) return cmd_tables((unsigned)atoi(argv[2]), atoll(argv[3]), atoi(argv[4]));
     if (cmd == "plan") return cmd_plan();
+    if (cmd == "floats" && argc == 3) {  // host_san floats N: float32 bit patterns (one hex word per line on stdin) -> text
+        char line[64], out[64];
+        long long n = atoll(argv[2]);
+        while (n-- > 0 && fgets(line, sizeof(line), stdin)) {
+            const uint32_t bits = (uint32_t)strtoul(line, nullptr, 16);
+            float x;
+            memcpy(&x, &bits, 4);
+            const int len = ovw::format_float32(x, out);
+            fwrite(out, 1, (size_t)len, stdout);
+            fputc('\n', stdout);
+        }
+        return 0;
+    }
+    if (cmd == "overlaps" && argc == 4) {  // host_san overlaps OUT THREADS: a random graph incl. -1 fillers, self hits, inf
+        std::mt19937_64 rng(7);
+        const int64_t n = 3000;
+        const int k = 11;
+        std::vector<int64_t> off((size_t)n + 1, 0);
+        std::string names;
+        std::vector<uint8_t> strands((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            names += "read_" + std::to_string(i / 2) + std::string((size_t)(rng() % 5), 'x');
+            off[(size_t)i + 1] = (int64_t)names.size();
+            strands[(size_t)i] = (uint8_t)(i & 1);
+        }
+        std::vector<int32_t> idx((size_t)(n * k));
+        std::vector<float> dist((size_t)(n * k));
+        for (int64_t i = 0; i < n * k; ++i) {
+            idx[(size_t)i] = (rng() % 50 == 0) ? -1 : (int32_t)(rng() % (uint64_t)n);
+            const uint32_t bits = (uint32_t)(rng() % 0x3f800001u);  // [0, 1]
+            memcpy(&dist[(size_t)i], &bits, 4);
+            if (rng() % 97 == 0) dist[(size_t)i] = std::numeric_limits<float>::infinity();
+        }
+        for (int64_t q = 0; q < n; q += 3) idx[(size_t)(q * k)] = (int32_t)q;
+        int64_t lines = 0, lines2 = 0;
+        // whole graph in one call, then the same graph as two row blocks appended to a second file
+        int rc = fdr_overlaps_write(argv[2], 0, 1, n, 0, n, k, idx.data(), dist.data(), off.data(), names.data(),
+                                    strands.data(), atoi(argv[3]), &lines);
+        const std::string p2 = std::string(argv[2]) + ".parts";
+        int64_t l1 = 0;
+        if (!rc) rc = fdr_overlaps_write(p2.c_str(), 0, 1, n, 0, 1000, k, idx.data(), dist.data(), off.data(), names.data(),
+                                         strands.data(), atoi(argv[3]), &l1);
+        if (!rc) rc = fdr_overlaps_write(p2.c_str(), 1, 0, n, 1000, n - 1000, k, idx.data() + 1000 * k, dist.data() + 1000 * k,
+                                         off.data(), names.data(), strands.data(), atoi(argv[3]), &lines2);
+        idx[5] = (int32_t)n;  // out of range: refused
+        const int rc_bad = fdr_overlaps_write((std::string(argv[2]) + ".bad").c_str(), 0, 1, n, 0, n, k, idx.data(), dist.data(),
+                                              off.data(), names.data(), strands.data(), 1, nullptr);
+        printf("rc=%d lines=%lld parts=%lld bad_rc=%d\n", rc, (long long)lines, (long long)(l1 + lines2), rc_bad);
+        return rc ? 1 : 0;
+    }
     if (cmd == "plan-print" && argc == 7) {  // host_san plan-print NQ NT D K SHAPE  (-1: the exact mode's choice)
         const KnnPlan p = knn_plan(256, atoll(argv[2]), atoll(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
         printf("shape=%d nqb=%d nseg=%d tiles:", p.shape, p.nqb, p.nseg);

@@ -153,3 +153,63 @@ def test_cli_from_reads_only(tmp_path, oracle):
     idx, dist = oracle.knn(E, 20)
     names = [i.decode() for i in s["ids"] for _ in (0, 1)]
     assert got == oracle.overlaps_tsv(idx, dist, names, [0, 1] * 600)
+
+
+def test_cli_devices_sharded_run_is_byte_identical(tmp_path):
+    """`--devices a,b,c` starts one process per entry BEFORE the parent touches a GPU; every rank embeds its
+    row block, the blocks are all-gathered, every rank searches its rows and writes its part, the parent
+    concatenates the parts.  Here the three ranks share GPU 0 over gloo (RCCL needs one GPU per rank): the
+    result must be the single-GPU overlaps.tsv byte for byte, incl. a ragged last block (1800 rows / 3
+    ranks in 32-row-aligned blocks)."""
+    import subprocess
+    import sys
+    s = synth(900, seed=5, m=80)
+    names = ["read_%d/ccs" % i for i in range(900)]
+    out_bin, fasta, L = _write_intermediates(tmp_path, s, names)
+    base = ["-n", "128", "--nndescent-n-neighbors", "20", "--kmer-searcher-output", out_bin, "--kmer-library", fasta]
+    one = tmp_path / "one"
+    cli.main(["-o", str(one)] + base)
+    many = tmp_path / "many"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "fedrann_amd", "-o", str(many), "--devices", "0,0,0", "--dist-backend",
+                        "gloo", "--keep-intermediates"] + base, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (many / "overlaps.tsv").read_bytes() == (one / "overlaps.tsv").read_bytes()
+    parts = sorted(p.name for p in (many / "temp").iterdir() if p.name.startswith("overlaps.rank"))
+    assert parts == ["overlaps.rank0.tsv", "overlaps.rank1.tsv", "overlaps.rank2.tsv"]
+
+
+def test_cli_fastq_headers_follow_the_fasta_id_rule(tmp_path, oracle):
+    """The reference converts FASTQ to FASTA (seqkit fq2fa, count_kmers.py:76-79) before kmer_searcher sees
+    it, so a read's name is its header up to the first space OR TAB: ONT / PacBio style descriptions and
+    samtools tags must not end up in overlaps.tsv (nor make the output.bin writer refuse the TAB)."""
+    from fedrann_amd.synth import synth_sequences
+    k = 15
+    s = synth_sequences(300, genome_len=60_000, mean_len=2000, k=k, sample=0.05, seed=53)
+    rng = np.random.default_rng(3)
+    counts = rng.integers(2, 40, size=len(s["fwd"]))
+    lib = tmp_path / "fwd_kmer_library.fasta"
+    lib.write_bytes(b"".join(b">%d\n%s\n" % (int(c), x) for c, x in zip(counts, s["fwd"])))
+    reads = [bytes(s["seqs"][s["seq_off"][i]:s["seq_off"][i + 1]]) for i in range(300)]
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "wb") as f:
+        for i, (rid, r) in enumerate(zip(s["ids"], reads)):
+            desc = b" runid=abc ch=%d" % i if i % 2 else b"\tRG:Z:x\tch=%d" % i
+            f.write(b"@" + rid + desc + b"\n" + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    fa = tmp_path / "reads.fasta"
+    fa.write_bytes(b"".join(b">%s\n%s\n" % (i, r) for i, r in zip(s["ids"], reads)))
+    outs = []
+    for path, tag in ((fq, "q"), (fa, "a")):
+        out_dir = tmp_path / ("out_" + tag)
+        cli.main(["-i", str(path), "-k", str(k), "-o", str(out_dir), "-n", "128", "--nndescent-n-neighbors", "20",
+                  "--kmer-library", str(lib)])
+        outs.append((out_dir / "overlaps.tsv").read_bytes())
+    assert outs[0] == outs[1] and b"runid" not in outs[0] and b"RG:Z" not in outs[0]
+    assert outs[0].count(b"\n") > 300
+
+
+def test_cli_refuses_unsupported_sizes_before_any_work(tmp_path):
+    for extra in (["-n", "1000"], ["--nndescent-n-neighbors", "100"]):
+        with pytest.raises(SystemExit) as e:
+            cli.main(["-o", str(tmp_path / "o"), "--feature-matrix", "missing.npz", "--kmer-counts", "missing.npy"] + extra)
+        assert "GPU k-NN kernels" in str(e.value)

@@ -1,0 +1,102 @@
+"""BASELINE.json configs 4 and 5 on the one GPU a test box has: ONE RANK'S SHARE of the 8-GPU runs through the
+device API (fdr_normalize_dev + fdr_knn_dev, what distributed.ShardedPipeline calls after the all-gather).
+
+  config 4: 10 M rows, d = 128, k = 20, rows sharded 1.25 M per GPU  -> queries = rows [0, 1.25 M) of 10 M targets
+  config 5: 10 M reads doubled (20 M rows), d = 256, k = 50          -> the same shape at 1 M doubled rows
+            (20 M x 256 needs the node's other seven GPUs' worth of time, not of memory: see the workspace test)
+
+The embeddings are made on the device (locus prototypes with a few non-zero components + per-read drop-outs:
+sparse rows, near-duplicates, exact duplicates, all-zero rows -- the structure of real projected k-mer
+profiles) because a 10 M-row CSR takes the host longer to synthesise than the GPU needs to search it.  Parity:
+a sample of query rows against the exact CPU oracle over ALL targets, bit for bit, + whole-result properties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_embeddings(n, d, nnz, loci, seed, doubling=False):
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rows = n // 2 if doubling else n
+    comp = torch.randint(0, d, (loci, nnz), device=dev, generator=g)
+    val = torch.randint(1, 9, (loci, nnz), device=dev, generator=g).float() * 0.37
+    val = val * (torch.randint(0, 2, (loci, nnz), device=dev, generator=g).float() * 2 - 1)
+    E = torch.zeros((n, d), dtype=torch.float32, device=dev)
+    step = 1 << 20
+    for lo in range(0, rows, step):
+        m = min(step, rows - lo)
+        locus = torch.randint(0, loci, (m,), device=dev, generator=g)
+        keep = (torch.rand((m, nnz), device=dev, generator=g) < 0.8).float()  # sequencing errors drop components
+        blk = torch.zeros((m, d), dtype=torch.float32, device=dev)
+        blk.scatter_add_(1, comp[locus], val[locus] * keep)
+        if doubling:  # row 2i = the read, row 2i + 1 = its strand mirror (here: the components reversed)
+            E[2 * lo:2 * (lo + m):2] = blk
+            E[2 * lo + 1:2 * (lo + m):2] = blk.flip(1)
+        else:
+            E[lo:lo + m] = blk
+    return E
+
+
+def _check_rank_share(ctx, oracle, E, nq, k, sample=256):
+    import torch
+    from fedrann_amd.distributed import HipEngine
+    dev = E.device
+    n, d = E.shape
+    eng = HipEngine(ctx, dev)
+    dp = ctx.padded_dim(d)
+    Ehat = torch.zeros((n, dp), dtype=torch.float32, device=dev)
+    zero = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    eng.normalize(E, Ehat, zero)
+    need = ctx.knn_workspace_bytes(nq, n, d, k)
+    assert need < 200e9
+    idx, dst = eng.knn(Ehat[:nq], zero[:nq], nq, Ehat, zero, n, d, k)
+    torch.cuda.synchronize(dev)
+    ut, uq = ctx.last_unique()
+    idx, dst = idx.cpu().numpy(), dst.cpu().numpy()
+    # whole-result properties: keys strictly ascending per row, indices in range, distances in [0, 1]
+    key = dst.view(np.uint32).astype(np.uint64) << np.uint64(32) | idx.astype(np.uint64)
+    assert np.all(key[:, 1:] > key[:, :-1])
+    assert idx.min() >= 0 and idx.max() < n and dst.min() >= 0 and dst.max() <= 1
+    # sampled exact oracle over ALL targets (incl. all-zero query rows and the block's first / last rows)
+    Eh_host, _, z_host = oracle.normalize(E.cpu().numpy())
+    rng = np.random.default_rng(1)
+    zr = np.flatnonzero(z_host[:nq])[:16]
+    rows = np.unique(np.concatenate([rng.choice(nq, size=sample, replace=False), zr, [0, 1, nq - 2, nq - 1]]))
+    wi, wd = oracle.knn_normalized(Eh_host[rows], z_host[rows], Eh_host, z_host, k)
+    assert np.array_equal(idx[rows], wi)
+    assert np.array_equal(dst[rows].view(np.uint32), wd.view(np.uint32))
+    return ut, uq
+
+
+def test_config4_one_rank_share_10m_targets(ctx, oracle):
+    """1.25 M query rows against 10 M targets, d = 128, k = 20: what each of the 8 ranks of config 4 runs after
+    the all-gather (22 target segments of <= 2^19 rows, duplicate-row classes over the full target set)."""
+    ctx.set_knn_mode("auto")
+    ctx.set_dedup_mode("auto")
+    E = _device_embeddings(10_000_000, 128, nnz=6, loci=4_000_000, seed=4)
+    ut, uq = _check_rank_share(ctx, oracle, E, 1_250_000, 20)
+    assert 20 <= ut <= 10_000_000 and uq <= 1_250_000
+
+
+def test_config5_shape_doubled_rows_d256_k50(ctx, oracle):
+    """Config 5's shape at 1 M doubled rows: d = 256 (DP = 256 kernels), k = 50 (K' = 58: the 2 x 32-key register
+    lists), fwd / mirrored row pairs; queries = one rank's eighth."""
+    ctx.set_knn_mode("auto")
+    ctx.set_dedup_mode("auto")
+    E = _device_embeddings(1_000_000, 256, nnz=8, loci=300_000, seed=5, doubling=True)
+    _check_rank_share(ctx, oracle, E, 125_000, 50)
+    _check_rank_share(ctx, oracle, E[:200_000].contiguous(), 200_000, 50, sample=128)  # and all-pairs at 200 k rows
+
+
+def test_per_rank_workspace_of_configs_4_and_5_fits_hbm(ctx):
+    """fdr_knn_workspace_bytes for one rank of config 4 (1.25 M x 10 M, d = 128, k = 20) and of config 5
+    (2.5 M x 20 M, d = 256, k = 50), plus the gathered embeddings and the results, against 288 GB of HBM."""
+    hbm = ctx.device_info()["hbm_bytes"]
+    assert hbm > 250e9
+    for nq, nt, d, k in ((1_250_000, 10_000_000, 128, 20), (2_500_000, 20_000_000, 256, 50)):
+        ws = ctx.knn_workspace_bytes(nq, nt, d, k)
+        total = ws + nt * ctx.padded_dim(d) * 4 + nt + nq * k * 8
+        assert 0 < ws and total < 0.9 * hbm, (nq, nt, d, k, ws, total)

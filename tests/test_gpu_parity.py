@@ -362,3 +362,57 @@ def test_errors_are_raised_not_swallowed(ctx):
     with pytest.raises(_lib.FedrannHipError):
         fresh.embed(np.array([0, 1], np.int64), np.array([0], np.int32))  # no projection loaded
     fresh.close()
+
+
+# ---- the certificate's error bound on adversarial rows ---------------------------------------------
+def _adversarial_rows(kind, n, d, rng):
+    if kind == "fp16_midpoints":
+        # components that sit (after normalisation, to within 1e-7) half way between two fp16 numbers:
+        # (1 + (2 m + 1) 2^-11) 2^e -- every operand rounds by the full half ulp, in a direction numpy's and
+        # the GPU's round-to-nearest-even must agree on
+        nnz = 6
+        E = np.zeros((n, d), np.float32)
+        for i in range(n):
+            c = rng.choice(d, size=nnz, replace=False)
+            m = rng.integers(0, 512, size=nnz)
+            e = rng.integers(-3, 0, size=nnz)
+            E[i, c] = (1.0 + (2 * m + 1) * 2.0 ** -11) * 2.0 ** e * rng.choice([-1.0, 1.0], size=nnz)
+        # rows drawn from a few component sets: many positive similarities, many near ties
+        E[n // 2:] = E[rng.integers(0, n // 2, size=n - n // 2)] * rng.choice([1.0, 0.5, 2.0], size=(n - n // 2, 1))
+        E[n // 2:, :] += (rng.random((n - n // 2, d)) < 0.01) * np.float32(0.25)
+        return E.astype(np.float32)
+    if kind == "fp16_subnormals":
+        # one or two dominant components and dozens below fp16's smallest normal number (6.1e-5) after
+        # normalisation: the fp16 copies lose them almost entirely
+        E = (rng.random((n, d)) < 0.3) * rng.uniform(1e-6, 5e-5, size=(n, d)) * rng.choice([-1.0, 1.0], size=(n, d))
+        for i in range(n):
+            c = rng.choice(d, size=2, replace=False)
+            E[i, c] = rng.choice([-1.0, 1.0], size=2) * rng.uniform(0.5, 1.0, size=2)
+        return E.astype(np.float32)
+    # dense rows: sum |x||y| = 1 for every pair, the fp32 accumulation term d 2^-24 is at its largest
+    base = rng.standard_normal((8, d))
+    E = base[rng.integers(0, 8, size=n)] + 0.3 * rng.standard_normal((n, d))
+    return E.astype(np.float32)
+
+
+@pytest.mark.parametrize("kind,d", [("fp16_midpoints", 128), ("fp16_subnormals", 128), ("dense", 512),
+                                    ("fp16_midpoints", 512)])
+def test_certificate_error_bound_on_adversarial_rows(ctx, oracle, knn_mode, kind, d):
+    """FDR_PREFILTER_EPS = 0.00105 must bound |fp16 similarity - canonical similarity| on ALL pairs of a
+    2000-row set built to stress it (knn_prefilter.inc's certificate rests on it), and the k-NN must still be
+    the oracle's bits."""
+    if not knn_mode.startswith("prefilter"):
+        pytest.skip("prefilter mode only")
+    rng = np.random.default_rng(d + len(kind))
+    E = _adversarial_rows(kind, 2000, d, rng)
+    Eh, _, zero = oracle.normalize(E)
+    assert not zero.any()
+    h = Eh.astype(np.float16).astype(np.float64)       # the operands the MFMA sees (round to nearest even)
+    approx = h @ h.T                                    # (its fp32 accumulation adds <= d 2^-24 <= 3.1e-5)
+    exact = Eh.astype(np.float64) @ Eh.astype(np.float64).T  # (the fp32 fma chain is within 1e-6 of this)
+    err = np.abs(approx - exact).max()
+    assert err + d * 2.0 ** -24 + 1e-6 < 0.00105, err
+    if kind == "fp16_midpoints":
+        assert err > 2e-4  # (the construction does push the error towards the bound)
+    for k in (20, 50):
+        _assert_knn_equal(ctx.knn(E, k), oracle.knn(E, k))

@@ -199,6 +199,68 @@ def test_overlaps_writer_is_byte_identical(tag):
     assert df["distance"].dtype == np.float32 and df["neighbor_rank"].dtype == np.int64
 
 
+@pytest.mark.parametrize("tag", ["overlaps_edge", "overlaps_rand"])
+def test_native_overlaps_writer_is_byte_identical_to_reference_output(tmp_path, tag):
+    """fdr_overlaps_write (no DataFrame, no pandas) against the TSVs the reference's own get_output_dataframe
+    + to_csv produced (tests/golden/make_golden.py): -1 aliasing, inf, 1.1920929e-07, 1.0, rank gaps."""
+    from fedrann_amd.__main__ import write_overlaps
+    g = np.load(golden(tag + ".npz"))
+    p = tmp_path / "o.tsv"
+    lines = write_overlaps(str(p), g["indices"], g["dist_bits"].view(np.float32), list(g["names"]),
+                           [int(s) for s in g["strands"]])
+    want = open(golden(tag + ".tsv"), "rb").read()
+    assert p.read_bytes() == want and lines == want.count(b"\n") - 1
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_native_overlaps_writer_equals_pandas_on_random_graphs(tmp_path, threads):
+    """Large enough for the thread pool; float32 distances over the whole range incl. values below 1e-4
+    (scientific layout), exact 0 / 1, inf; rows written whole and as two appended blocks."""
+    from fedrann_amd import _lib, global_variables
+    from fedrann_amd.__main__ import write_overlaps
+    rng = np.random.default_rng(4)
+    n, k = 9000, 12
+    idx = rng.integers(0, n, size=(n, k)).astype(np.int32)
+    idx[::3, 0] = np.arange(n)[::3]
+    idx[rng.random((n, k)) < 0.01] = -1
+    dist = rng.integers(0, 0x3f800001, size=(n, k), dtype=np.uint32).view(np.float32).copy()
+    dist[rng.random((n, k)) < 0.02] = np.inf
+    dist[0, :4] = [0.0, 1.0, 1e-4, 9.9999e-05]
+    names = ["r%d/%s" % (i // 2, "ab"[i % 2] * (i % 5)) for i in range(n)]
+    strands = [i % 2 for i in range(n)]
+    df = get_output_dataframe(idx, dist, names, strands)
+    buf = io.StringIO()
+    df.to_csv(buf, sep="\t", index=False)
+    want = buf.getvalue().encode()
+    global_variables.threads = threads
+    try:
+        p = tmp_path / "o.tsv"
+        assert write_overlaps(str(p), idx, dist, names, strands) == df.shape[0]
+        assert p.read_bytes() == want
+        q = tmp_path / "parts.tsv"
+        off, buf8 = _lib.pack_names(names)
+        a = _lib.overlaps_write(str(q), idx[:4000], dist[:4000], off, buf8, np.array(strands, np.uint8), row0=0)
+        b = _lib.overlaps_write(str(q), idx[4000:], dist[4000:], off, buf8, np.array(strands, np.uint8), row0=4000,
+                                append=True, header=False)
+        assert q.read_bytes() == want and a + b == df.shape[0]
+    finally:
+        global_variables.threads = 1
+    with pytest.raises(_lib.FedrannHipError):
+        bad = idx.copy()
+        bad[5, 5] = n
+        write_overlaps(str(tmp_path / "bad.tsv"), bad, dist, names, strands)
+
+
+def test_fastq_ids_on_pipeline_paths(tmp_path):
+    from fedrann_amd.kmer_search import read_sequences
+    fq = tmp_path / "r.fastq"
+    fq.write_bytes(b"@id1 runid=9 ch=3\nACGT\n+\nIIII\n@id2\tRG:Z:a\nGG\n+\nII\n@ only_description\nTT\n+\nII\n@id4\nA\n+\nI\n")
+    ids, seqs, off = read_sequences(str(fq))  # the stand-alone tool keeps the whole header (kmer_searcher.cpp:186)
+    assert ids == [b"id1 runid=9 ch=3", b"id2\tRG:Z:a", b" only_description", b"id4"]
+    ids, seqs, off = read_sequences(str(fq), fastq_ids_as_fasta=True)  # pipeline: after seqkit fq2fa
+    assert ids == [b"id1", b"id2", b"id4"] and bytes(seqs) == b"ACGTGGA" and off.tolist() == [0, 4, 6, 7]
+
+
 def test_overlaps_writer_equals_oracle_loop(oracle):
     rng = np.random.default_rng(8)
     n, k = 57, 9

@@ -118,3 +118,15 @@ def test_loader_errors_under_sanitizers_match_library(san, tmp_path):
     assert int(_fields(san("loader", p, 9, 1))["rc"]) == -1  # odd n_features
     # the file changed between scan and load (capacities no longer match): refused before any write
     assert int(_fields(san("loader-stale", p, 10))["rc"]) == -5  # FDR_E_STATE
+
+
+def test_overlaps_writer_under_sanitizers(san, tmp_path):
+    """A 3000-row graph with -1 fillers, self hits and inf, written whole and as two appended row blocks (1 and
+    5 threads): same bytes; an out-of-range neighbour index is refused."""
+    for threads in (1, 5):
+        out = tmp_path / ("o%d.tsv" % threads)
+        f = _fields(san("overlaps", out, threads))
+        assert f["rc"] == "0" and f["lines"] == f["parts"] and f["bad_rc"] == "-1"
+        assert out.read_bytes() == (tmp_path / ("o%d.tsv.parts" % threads)).read_bytes()
+        assert out.read_bytes().count(b"\n") == int(f["lines"]) + 1
+    assert (tmp_path / "o1.tsv").read_bytes() == (tmp_path / "o5.tsv").read_bytes()
