@@ -172,7 +172,9 @@ int fdr_last_uncertified(fdr_ctx *ctx);
  * outside ACGTacgt makes every window that contains it invalid in the reference's particular way (see
  * kmer_search.inc).  Output: CSR rows of ascending unique library indices per read (the reference
  * writes them in hash-set order): indptr_out int64 [n_reads + 1] and *nnz_out from fdr_kmer_search,
- * then the indices (int32 [nnz], kept on the device until then) from fdr_kmer_search_indices. */
+ * then the indices (int32 [nnz], kept on the device until then) from fdr_kmer_search_indices, which also
+ * releases the search's device scratch (~28 B per base: not to be held through the embed / k-NN stages).
+ * Limits: the concatenated reads must be shorter than 2^32 characters and, with that scratch, fit in HBM. */
 int fdr_kmer_search(fdr_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, int64_t n_reads,
                     const uint64_t *lib_codes, int64_t n_lib, int32_t k, int64_t *indptr_out,
                     int64_t *nnz_out);
@@ -184,7 +186,8 @@ int fdr_kmer_search_indices(fdr_ctx *ctx, int32_t *indices_out);
  * the smaller of its 2-bit code and its reverse complement's.  fdr_kmer_count keeps the k-mers with at
  * least min_count occurrences on the device and returns their number; fdr_kmer_count_fetch copies
  * them out in ascending code order (jellyfish dumps in its hash order; the order only names the
- * features): codes_out, counts_out uint64 [n]. */
+ * features): codes_out, counts_out uint64 [n], and releases the device scratch.  Same size limits as
+ * fdr_kmer_search. */
 int fdr_kmer_count(fdr_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, int64_t n_reads, int32_t k,
                    int64_t min_count, int64_t *n_out);
 int fdr_kmer_count_fetch(fdr_ctx *ctx, uint64_t *codes_out, uint64_t *counts_out);

@@ -416,3 +416,18 @@ def test_certificate_error_bound_on_adversarial_rows(ctx, oracle, knn_mode, kind
         assert err > 2e-4  # (the construction does push the error towards the bound)
     for k in (20, 50):
         _assert_knn_equal(ctx.knn(E, k), oracle.knn(E, k))
+
+
+@pytest.mark.parametrize("k", [30, 31, 33, 34, 36])
+def test_exact_mode_retry_pass_on_the_distance_one_plateau(ctx, oracle, knn_mode, k):
+    """Rows whose similarities are mostly <= 0 (distance clamped to exactly 1.0): the k-th neighbour of many
+    queries sits on the plateau, decided by the index alone, and with k in 30..36 (two-entry append queues)
+    the queues overflow in the middle of a tile, so the exact kernel's retry pass must admit dist == tau == 1
+    candidates whose similarity is far below the similarity-space gate."""
+    rng = np.random.default_rng(100 + k)
+    n, d = 3000, 96
+    E = np.zeros((n, d), np.float32)
+    for i in range(n):  # two or three components per row, signs mixed: most pairs have sim <= 0 or no overlap
+        c = rng.choice(d, size=rng.integers(2, 4), replace=False)
+        E[i, c] = rng.choice([-1.0, 1.0], size=c.size) * rng.uniform(0.5, 1.5, size=c.size)
+    _assert_knn_equal(ctx.knn(E, k), oracle.knn(E, k))
