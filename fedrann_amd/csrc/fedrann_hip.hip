@@ -642,6 +642,15 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     const int ib = prefilter_index_bits(max_seg);
     if (ib > FDR_PREFILTER_MAX_IB) return fail(FDR_E_ARG, "knn prefilter: segment of %d rows", max_seg);
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
+#ifdef FDR_DEV
+    if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_WARM", 0) != 0) {
+        // experiment: an untimed first pass leaves every query's FINAL bound in d_shared; the timed pass below
+        // then starts warm -- what a perfect pre-pass could buy
+        hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)p.nqb, (unsigned)p.nseg),
+                           dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad,
+                           d_partial, d_shared, ib FDR_DBG_ARG(0));
+    }
+#endif
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     const int pdbg = dev_env_int("FDR_KNN_DEBUG", 0);
     (void)pdbg;

@@ -17,7 +17,11 @@
  *   - the caller owns every buffer it passes; the library borrows pointers for the duration of the
  *     call only.  "host" functions take host pointers and synchronise before returning; "_dev"
  *     functions take device pointers (hipMalloc'd or a torch tensor's data_ptr()) plus a
- *     hipStream_t passed as void*, enqueue work on that stream and return without synchronising.
+ *     hipStream_t passed as void* and enqueue work on that stream.  fdr_embed_dev and fdr_normalize_dev
+ *     return without synchronising; fdr_knn_dev synchronises the stream up to four times (it sizes its
+ *     follow-up passes from counters it reads back: duplicate-row probe, unique-row counts, uncertified /
+ *     all-zero / plateau queries, overflowing ranges), so work the caller wants to overlap with it
+ *     belongs on another stream.
  *   - one context = one GPU; one context per process is the intended use (one process per GPU).
  *     A context is not re-entrant: one call in flight at a time.
  *   - all arrays are C-contiguous with exactly the element types written here.
@@ -113,7 +117,8 @@ int fdr_normalize_dev(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int32_t d,
 size_t fdr_knn_workspace_bytes(fdr_ctx *ctx, int64_t nq, int64_t nt, int32_t d, int32_t k);
 /* k-NN of nq query rows against nt target rows, both in the Ehat layout.  Neighbour indices are
  * target row numbers + t_base.  Rows of a row-sharded run: queries = the rank's shard, targets =
- * the all-gathered Ehat of every rank. */
+ * the all-gathered Ehat of every rank.  The result arrays are complete when the call returns AND the
+ * stream has finished (see "Conventions": the call itself waits for the stream a few times). */
 int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
                 const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int32_t d,
                 int32_t k, int32_t *d_idx, float *d_dist, void *d_workspace, size_t workspace_bytes,
