@@ -501,7 +501,10 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.chunk = (int)std::min<int64_t>(nq, 16384);
     const size_t exact_all = knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
     const int dp = fdr_padded_dim(d);
-    const size_t pre = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp)).total_bytes;
+    const KnnPlan pp = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp));
+    // (a later call on fewer unique rows may plan more, shorter segments: room for the largest such plan)
+    const size_t pre = std::max(pp.total_bytes, pp.bits_bytes + pp.shared_bytes +
+                                                    prefilter_partial_bound(nq, nt, L.kp, pp.qw));
     // any exact plan for <= chunk queries: bits + bound words + at most FDR_MAX_SEG segments of lists
     const size_t chunk_bound = align256((size_t)((nt + 31) / 32) * 4) + align256((size_t)(L.chunk + 128) * 4) +
                                (size_t)FDR_MAX_SEG * (L.chunk + 128) * (size_t)k * 8;
@@ -646,21 +649,26 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_WARM", 0) != 0) {
         // experiment: an untimed first pass leaves every query's FINAL bound in d_shared; the timed pass below
         // then starts warm -- what a perfect pre-pass could buy
-        hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)p.nqb, (unsigned)p.nseg),
+        hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)(p.nqb * p.nseg)),
                            dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad,
-                           d_partial, d_shared, ib FDR_DBG_ARG(0));
+                           d_partial, d_shared, ib, 0, p.nqb FDR_DBG_ARG(0));
     }
 #endif
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     const int pdbg = dev_env_int("FDR_KNN_DEBUG", 0);
     (void)pdbg;
-#define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_)                                                   \
-    do { /* (the ring is at most 32 KB: no dynamic-LDS attribute needed) */                             \
-        hipLaunchKernelGGL((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>),                        \
-                           dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(64 * NW_), lds, st, d_hq, (int)nq, \
-                           d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, d_shared, ib    \
-                           FDR_DBG_ARG(pdbg));                                                          \
+    // the nqb * nseg work items in launches of p.cohort workgroups (0: one launch): see knn_plan_compute
+    const long long n_items = (long long)p.nqb * p.nseg;
+    const long long per_launch = p.cohort > 0 ? p.cohort : n_items;
+#define FDR_LAUNCH_PRE3(KERNEL_, THREADS_)                                                              \
+    do {                                                                                                \
+        for (long long base_ = 0; base_ < n_items; base_ += per_launch)                                 \
+            hipLaunchKernelGGL(KERNEL_, dim3((unsigned)std::min(per_launch, n_items - base_)), dim3(THREADS_), lds, \
+                               st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, \
+                               d_shared, ib, (int)base_, p.nqb FDR_DBG_ARG(pdbg));                        \
     } while (0)
+#define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_) /* (the ring is at most 32 KB: no dynamic-LDS attribute) */ \
+    FDR_LAUNCH_PRE3((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>), 64 * NW_)
 #define FDR_LAUNCH_PRE(DP_, NQ_, NW_, WPS_, U_)                                                         \
     do {                                                                                                \
         if (kp <= 32) FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 16);                                     \
@@ -678,12 +686,11 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_PAIR", 1) != 0) {
         // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
         // <= 128 VGPRs.  FDR_KNN_PAIR=0: development knob, one chain)
-        hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)p.nqb, (unsigned)p.nseg),
-                           dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad,
-                           d_partial, d_shared, ib FDR_DBG_ARG(pdbg));
+        FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
     } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
     else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
     else FDR_LAUNCH_PRE(512, 1, 4, 2, 2);
+#undef FDR_LAUNCH_PRE3
 #undef FDR_LAUNCH_PRE2
 #undef FDR_LAUNCH_PRE
     HIP_TRY(hipGetLastError());

@@ -163,7 +163,8 @@ static int check_plan(int cus, int64_t nq, int64_t nt, int d, int k, int shape) 
     }
     ok = ok && p.segs.b[p.nseg] == T * 32;
     for (int i = p.nseg; i <= FDR_MAX_SEG && ok; ++i) ok = p.segs.b[i] == T * 32;
-    ok = ok && p.total_bytes == p.bits_bytes + p.shared_bytes + p.partial_bytes &&
+    ok = ok && p.cohort >= 0 && (p.cohort == 0 || (p.cohort <= cus * 4 && sh.tps > 0)) &&
+         p.total_bytes == p.bits_bytes + p.shared_bytes + p.partial_bytes &&
          p.partial_bytes == (size_t)p.nseg * p.nq_pad * (size_t)k * 8;
     if (!ok) printf("FAIL plan cus=%d nq=%lld nt=%lld d=%d k=%d shape=%d nseg=%d\n", cus, (long long)nq, (long long)nt, d, k, shape, p.nseg);
     return ok ? 0 : 1;
@@ -255,7 +256,7 @@ int main(int argc, char **argv) {
     }
     if (cmd == "plan-print" && argc == 7) {  // host_san plan-print NQ NT D K SHAPE  (-1: the exact mode's choice)
         const KnnPlan p = knn_plan(256, atoll(argv[2]), atoll(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
-        printf("shape=%d nqb=%d nseg=%d tiles:", p.shape, p.nqb, p.nseg);
+        printf("shape=%d nqb=%d nseg=%d cohort=%d tiles:", p.shape, p.nqb, p.nseg, p.cohort);
         for (int i = 0; i < p.nseg; ++i) printf(" %d", (p.segs.b[i + 1] - p.segs.b[i]) / 32);
         printf(" bytes=%zu\n", p.total_bytes);
         return 0;
