@@ -287,6 +287,7 @@ def main():
         if o_cnt["knn_prefilter"] > 0 or other_mode == "exact":
             other = {"mode": other_mode, "value": n * k * o_steps / o_elapsed, "unit": "read-pairs/s",
                      "steps": o_steps, "ms_per_step": o_elapsed / o_steps * 1e3, "kernels_ms": o_ms,
+                     "kernel_launches": o_cnt,
                      "identical_to_timed_run": same}
         ctx.set_knn_mode(args.mode)
 
@@ -335,17 +336,18 @@ def main():
         # actually evaluated, 2*d flop each (= all nloc * n pairs when the class layer did not engage)
         flops = 2.0 * uniq_q * uniq_t * d
 
-        def mfma_roofline(kms, prefilter):
+        def mfma_roofline(kms, kcnt, prefilter):
             name, peak = ("knn_prefilter", MFMA_F16_PEAK_TFLOPS) if prefilter else ("knn_tile", MFMA_F32_PEAK_TFLOPS)
-            ms = kms[name]
+            ms = kms[name]  # per step: the pass is one launch, or (synchronised rounds) several equal ones
+            launches = max(1.0, kcnt[name])
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return {"kernel": ("knn_prefilter_kernel (fp16 MFMA 32x32x16)" if prefilter
                                else "knn_tile_kernel<%d> (fp32 MFMA 32x32x2)" % ctx.padded_dim(d)),
                     "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                    "flops_per_launch": flops, "avg_launch_ms": ms}
+                    "launches_per_step": launches, "flops_per_launch": flops / launches,
+                    "avg_launch_ms": ms / launches, "ms_per_step": ms}
 
-        roof = mfma_roofline(kernel_ms, used_prefilter)
-        achieved, knn_ms = roof["achieved"], roof["avg_launch_ms"]
+        roof = mfma_roofline(kernel_ms, kernel_cnt, used_prefilter)
         nnz_loc = int(ix.size)
         embed_bytes = 4.0 * nnz_loc + 8.0 * nloc + 4.0 * nloc * d
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled as the
@@ -390,7 +392,7 @@ def main():
                                "note": "4 B per column id of the compacted CSR + 8 B per row pointer + 4 d B per row of E"},
         }
         if other is not None:
-            other["roofline"] = mfma_roofline(other["kernels_ms"], other["mode"] == "prefilter")
+            other["roofline"] = mfma_roofline(other["kernels_ms"], other["kernel_launches"], other["mode"] == "prefilter")
             result["other_mode"] = other
         if world == 1 and args.cpu_baseline_seconds > 0:
             m = min(nloc, 1 << 17)

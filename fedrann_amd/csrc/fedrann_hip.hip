@@ -654,7 +654,6 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                            d_partial, d_shared, ib, 0, p.nqb FDR_DBG_ARG(0));
     }
 #endif
-    if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     const int pdbg = dev_env_int("FDR_KNN_DEBUG", 0);
     (void)pdbg;
     // the nqb * nseg work items in launches of p.cohort workgroups (0: one launch): see knn_plan_compute
@@ -662,10 +661,13 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     const long long per_launch = p.cohort > 0 ? p.cohort : n_items;
 #define FDR_LAUNCH_PRE3(KERNEL_, THREADS_)                                                              \
     do {                                                                                                \
-        for (long long base_ = 0; base_ < n_items; base_ += per_launch)                                 \
+        for (long long base_ = 0; base_ < n_items; base_ += per_launch) { /* (every launch its own timed span) */ \
+            if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;                    \
             hipLaunchKernelGGL(KERNEL_, dim3((unsigned)std::min(per_launch, n_items - base_)), dim3(THREADS_), lds, \
                                st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, \
                                d_shared, ib, (int)base_, p.nqb FDR_DBG_ARG(pdbg));                        \
+            if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;                      \
+        }                                                                                               \
     } while (0)
 #define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_) /* (the ring is at most 32 KB: no dynamic-LDS attribute) */ \
     FDR_LAUNCH_PRE3((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>), 64 * NW_)
@@ -678,9 +680,11 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if (pshape == FDR_SHAPE_PREFILTER2) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter2_kernel<16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
         hipLaunchKernelGGL((knn_prefilter2_kernel<16>), dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(256), lds, st,
                            d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, d_shared,
                            ib FDR_DBG_ARG(pdbg));
+        if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     } else
 #endif
     if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_PAIR", 1) != 0) {
@@ -705,7 +709,6 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_counters), z, sizeof(z)));
     }
 #endif
-    if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
 
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
     hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,

@@ -131,7 +131,8 @@ int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64
 #define FDR_KERNEL_NORMALIZE 1
 #define FDR_KERNEL_KNN_TILE 2
 #define FDR_KERNEL_KNN_MERGE 3
-#define FDR_KERNEL_KNN_PREFILTER 4 /* fp16 MFMA candidate kernel of the prefilter mode */
+#define FDR_KERNEL_KNN_PREFILTER 4 /* fp16 MFMA candidate kernel of the prefilter mode (one span per launch: the pass
+                                      runs as several launches of one workgroup per resident slot on large inputs) */
 #define FDR_KERNEL_KNN_RERANK 5    /* rest of the prefilter mode: fp16 conversion, key merge, certificate +
                                       exact fp32 re-rank (two timed spans per call) */
 #define FDR_KERNEL_KNN_DEDUP 6     /* duplicate-row classes: hash, sort, class tables, gathers, expansion */
