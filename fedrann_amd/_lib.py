@@ -18,7 +18,7 @@ SYMBOLS = (
     "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_set_dedup_mode", "fdr_last_unique", "fdr_kmer_output_scan",
     "fdr_kmer_output_load", "fdr_kmer_search", "fdr_kmer_search_indices", "fdr_kmer_count",
     "fdr_kmer_count_fetch", "fdr_csr_compact", "fdr_host_register", "fdr_host_unregister",
-    "fdr_overlaps_write",
+    "fdr_overlaps_write", "fdr_last_prefilter_launches",
 )
 FDR_MAX_K = 64
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
@@ -84,6 +84,7 @@ def load_library():
     L.fdr_set_knn_mode.argtypes = [vp, ctypes.c_int]
     L.fdr_set_dedup_mode.argtypes = [vp, ctypes.c_int]
     L.fdr_last_unique.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.fdr_last_prefilter_launches.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     p64 = ctypes.POINTER(ctypes.c_int64)
     L.fdr_kmer_output_scan.argtypes = [ctypes.c_char_p, p64, p64, p64]
     L.fdr_kmer_output_load.argtypes = [ctypes.c_char_p, i64, i32, i64, i64, i64, vp, vp, vp, vp]
@@ -265,6 +266,13 @@ class Context:
         """(unique target rows, unique query rows) searched by the last k-NN call."""
         a, b = ctypes.c_int(), ctypes.c_int()
         self._check(self._L.fdr_last_unique(self._h, ctypes.byref(a), ctypes.byref(b)), "fdr_last_unique")
+        return int(a.value), int(b.value)
+
+    def last_prefilter_launches(self):
+        """(launches, queues) of the fp16 candidate pass of the last k-NN call (0, 0 after an exact-mode call)."""
+        a, b = ctypes.c_int(), ctypes.c_int()
+        self._check(self._L.fdr_last_prefilter_launches(self._h, ctypes.byref(a), ctypes.byref(b)),
+                    "fdr_last_prefilter_launches")
         return int(a.value), int(b.value)
 
     def last_uncertified(self):

@@ -213,6 +213,8 @@ struct fdr_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // further queues for the prefilter pass's launches
+    hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // [0] fork, [1..3] joins
     hipDeviceProp_t prop;
     // projection
     long long n_features = 0;
@@ -232,6 +234,7 @@ struct fdr_ctx {
     int dedup_mode = FDR_DEDUP_AUTO;
     int last_flagged = 0;  // prefilter mode: queries of the last call that took the exact path
     int last_unique_targets = 0, last_unique_queries = 0;  // duplicate-row classes of the last call
+    int last_pass_launches = 0, last_pass_queues = 0;      // prefilter pass of the last call
     bool timing = false;
     std::vector<hipEvent_t> ev_pool[FDR_NUM_KERNELS];  // start, stop, start, stop, ...
     size_t ev_used[FDR_NUM_KERNELS] = {};
@@ -309,6 +312,10 @@ FDR_EXPORT int fdr_destroy(fdr_ctx *ctx) {
     for (int i = 0; i < FDR_NUM_KERNELS; ++i)
         for (hipEvent_t e : ctx->ev_pool[i]) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
+    for (hipStream_t a : ctx->aux_stream)
+        if (a) (void)hipStreamDestroy(a);
+    for (hipEvent_t e : ctx->aux_ev)
+        if (e) (void)hipEventDestroy(e);
     delete ctx;
     return FDR_OK;
 }
@@ -326,6 +333,13 @@ FDR_EXPORT int fdr_last_unique(fdr_ctx *ctx, int *unique_targets, int *unique_qu
     if (!ctx || !unique_targets || !unique_queries) return fail(FDR_E_ARG, "bad argument");
     *unique_targets = ctx->last_unique_targets;
     *unique_queries = ctx->last_unique_queries;
+    return FDR_OK;
+}
+
+FDR_EXPORT int fdr_last_prefilter_launches(fdr_ctx *ctx, int *launches, int *queues) {
+    if (!ctx || !launches || !queues) return fail(FDR_E_ARG, "bad argument");
+    *launches = ctx->last_pass_launches;
+    *queues = ctx->last_pass_queues;
     return FDR_OK;
 }
 
@@ -659,14 +673,36 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     // the nqb * nseg work items in launches of p.cohort workgroups (0: one launch): see knn_plan_compute
     const long long n_items = (long long)p.nqb * p.nseg;
     const long long per_launch = p.cohort > 0 ? p.cohort : n_items;
+    // Several queues: with the launches of the synchronised rounds dealt round-robin to the caller's stream and
+    // further ones, the workgroups of a later launch take the slots the stragglers of an earlier one have
+    // freed (one queue: every launch ends with its slowest workgroup while the rest of the chip idles).
+    const int nqueues = p.cohort > 0 && n_items > per_launch ? std::max(1, std::min(p.queues, 4)) : 1;
+    ctx->last_pass_launches = (int)((n_items + per_launch - 1) / per_launch);
+    ctx->last_pass_queues = nqueues;
+    // one timed span for the whole pass when launches overlap (their own spans would count the same time twice)
+    if (nqueues > 1 && (trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
+    hipStream_t qs[4] = {st, st, st, st};
+    if (nqueues > 1) {
+        if (!ctx->aux_ev[0]) {
+            for (hipStream_t &a : ctx->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+            for (hipEvent_t &e : ctx->aux_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(ctx->aux_ev[0], st));  // the pass's inputs are ready on `st`
+        for (int q = 1; q < nqueues; ++q) {
+            qs[q] = ctx->aux_stream[q - 1];
+            HIP_TRY(hipStreamWaitEvent(qs[q], ctx->aux_ev[0], 0));
+        }
+    }
 #define FDR_LAUNCH_PRE3(KERNEL_, THREADS_)                                                              \
     do {                                                                                                \
-        for (long long base_ = 0; base_ < n_items; base_ += per_launch) { /* (every launch its own timed span) */ \
-            if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;                    \
+        int li_ = 0;                                                                                    \
+        for (long long base_ = 0; base_ < n_items; base_ += per_launch, ++li_) { /* (every launch its own timed span) */ \
+            hipStream_t ls_ = qs[li_ % nqueues];                                                        \
+            if (nqueues == 1 && (trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, ls_))) return trc;   \
             hipLaunchKernelGGL(KERNEL_, dim3((unsigned)std::min(per_launch, n_items - base_)), dim3(THREADS_), lds, \
-                               st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, \
-                               d_shared, ib, (int)base_, p.nqb FDR_DBG_ARG(pdbg));                        \
-            if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;                      \
+                               ls_, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, \
+                               d_shared, ib, (int)base_, p.nqb FDR_DBG_ARG(pdbg));                       \
+            if (nqueues == 1 && (trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, ls_))) return trc;     \
         }                                                                                               \
     } while (0)
 #define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_) /* (the ring is at most 32 KB: no dynamic-LDS attribute) */ \
@@ -698,6 +734,11 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
 #undef FDR_LAUNCH_PRE2
 #undef FDR_LAUNCH_PRE
     HIP_TRY(hipGetLastError());
+    for (int q = 1; q < nqueues; ++q) {  // the merge below (on `st`) needs the other queues' launches too
+        HIP_TRY(hipEventRecord(ctx->aux_ev[q], qs[q]));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_ev[q], 0));
+    }
+    if (nqueues > 1 && (trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
 #ifdef FDR_DEBUG_COUNTERS
     if (pdbg & 2) {
         unsigned long long c[8];
@@ -810,6 +851,7 @@ static int launch_knn_mode(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_q
         return launch_knn_prefilter(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx,
                                     d_dist, d_ws, ws_bytes, st);
     ctx->last_flagged = 0;  // (exact mode certifies nothing)
+    ctx->last_pass_launches = ctx->last_pass_queues = 0;
     return launch_knn_exact(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
                             d_ws, ws_bytes, st);
 }

@@ -131,8 +131,8 @@ int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64
 #define FDR_KERNEL_NORMALIZE 1
 #define FDR_KERNEL_KNN_TILE 2
 #define FDR_KERNEL_KNN_MERGE 3
-#define FDR_KERNEL_KNN_PREFILTER 4 /* fp16 MFMA candidate kernel of the prefilter mode (one span per launch: the pass
-                                      runs as several launches of one workgroup per resident slot on large inputs) */
+#define FDR_KERNEL_KNN_PREFILTER 4 /* fp16 MFMA candidate pass of the prefilter mode: one span per launch, or one span
+                                      over the whole pass when its launches overlap (fdr_last_prefilter_launches) */
 #define FDR_KERNEL_KNN_RERANK 5    /* rest of the prefilter mode: fp16 conversion, key merge, certificate +
                                       exact fp32 re-rank (two timed spans per call) */
 #define FDR_KERNEL_KNN_DEDUP 6     /* duplicate-row classes: hash, sort, class tables, gathers, expansion */
@@ -166,6 +166,10 @@ int fdr_set_dedup_mode(fdr_ctx *ctx, int mode);
 /* Unique target / query rows the most recent k-NN call
  * actually searched (= the row counts when the call found too few duplicates to bother). */
 int fdr_last_unique(fdr_ctx *ctx, int *unique_targets, int *unique_queries);
+/* Prefilter mode only: how the fp16 candidate pass of the most recent k-NN call was launched -- the number
+ * of kernel launches and of queues they were dealt to (with two queues two launches are in flight at any
+ * time and FDR_KERNEL_KNN_PREFILTER is ONE timed span over the whole pass; 0 / 0 after an exact-mode call). */
+int fdr_last_prefilter_launches(fdr_ctx *ctx, int *launches, int *queues);
 /* Prefilter mode only: number of query rows of the most recent k-NN call whose candidate set could
  * not be certified and that were therefore searched by the exact kernel. */
 int fdr_last_uncertified(fdr_ctx *ctx);
