@@ -10,7 +10,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fedrann_amd import _lib, global_variables  # noqa: E402
+from fedrann_amd import _lib  # noqa: E402
 from fedrann_amd.__main__ import get_output_dataframe, write_overlaps  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
@@ -24,18 +24,18 @@ names = ["read_%07d" % (i // 2) for i in range(n)]
 strands = [i % 2 for i in range(n)]
 tmp = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 try:
+    off, buf = _lib.pack_names(names)
+    st8 = np.array(strands, np.uint8)
     for threads in (1, 4, 16, 0):
-        global_variables.threads = threads if threads else 2  # (write_overlaps: > 1 -> that many, else all)
         t0 = time.perf_counter()
-        if threads == 0:
-            off, buf = _lib.pack_names(names)
-            lines = _lib.overlaps_write(os.path.join(tmp, "o.tsv"), idx, dist, off, buf, np.array(strands, np.uint8))
-        else:
-            lines = write_overlaps(os.path.join(tmp, "o.tsv"), idx, dist, names, strands)
+        lines = _lib.overlaps_write(os.path.join(tmp, "o.tsv"), idx, dist, off, buf, st8, n_threads=threads)
         dt = time.perf_counter() - t0
         size = os.path.getsize(os.path.join(tmp, "o.tsv"))
-        print("native writer, %s threads: %d lines, %.1f MB in %.2f s = %.1f M lines/s (incl. packing %d names)"
-              % (threads or "all", lines, size / 1e6, dt, lines / dt / 1e6, n))
+        print("native writer, %s threads: %d lines, %.1f MB in %.2f s = %.1f M lines/s"
+              % (threads or "all", lines, size / 1e6, dt, lines / dt / 1e6))
+    t0 = time.perf_counter()
+    write_overlaps(os.path.join(tmp, "o.tsv"), idx, dist, names, strands)
+    print("write_overlaps (packs %d Python names first, all threads): %.2f s" % (n, time.perf_counter() - t0))
     m = min(n, 100_000)  # pandas on a tenth (it is linear)
     t0 = time.perf_counter()
     df = get_output_dataframe(idx[:m] % m, dist[:m], names[:m], strands[:m])
