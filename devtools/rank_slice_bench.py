@@ -1,5 +1,7 @@
-"""Time what ONE rank of an N-rank run does after the all-gather (k-NN of its row block against all rows),
-for N = 1, 2, 4, 8, on a single GPU -- a model of the strong-scaling curve without RCCL.
+"""Time what ONE rank of an N-rank run does after the all-gather, for N = 1, 2, 4, 8, on a single GPU -- a model
+of the strong-scaling curve without RCCL.  Two variants: the k-NN of the rank's ROW block against all rows
+(fdr_knn_dev), and what distributed.ShardedPipeline does when the rows repeat: classes of all rows, k-NN of the
+rank's share of the UNIQUE rows, expansion of its own rows (the exchange of the shares is not timed).
 usage: python devtools/rank_slice_bench.py [reads] [N,N,...]"""
 import os
 import sys
@@ -46,3 +48,27 @@ for G in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1,
     base = base or ms
     print("N=%d: %6d query rows per rank, k-NN %.3f ms  (x%.2f vs N=1, ideal x%d)  %s"
           % (G, hi - lo, ms, base / ms, G, {a: b for a, b in kinds.items() if b}))
+    if G > 1:
+        nq_max = -(-n // G)
+        nu = eng.knn_classes(Ehat, zero, n, d, k, nq_max)
+        if nu > 0:
+            Su = -(-nu // G)
+            iu = torch.zeros((Su * G, k), dtype=torch.int32, device=dev)
+            du = torch.zeros((Su * G, k), dtype=torch.float32, device=dev)
+
+            def unique_step():
+                eng.knn_classes(Ehat, zero, n, d, k, nq_max)
+                eng.knn_unique(0, min(nu, Su), k, iu, du)
+                return eng.knn_expand(lo, hi - lo, k, iu, du)
+            unique_step()
+            torch.cuda.synchronize(dev)
+            ctx.timing(True)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                unique_step()
+            torch.cuda.synchronize(dev)
+            ms2 = (time.perf_counter() - t0) / 5 * 1e3
+            kinds = {name: round(ctx.timing_read(i)[1] / 5, 3) for i, name in enumerate(_lib.KERNELS)}
+            ctx.timing(False)
+            print("     unique-row split: %d of %d unique rows per rank, classes + k-NN + expansion %.3f ms  (x%.2f vs N=1)  %s"
+                  % (min(nu, Su), nu, ms2, base / ms2, {a: b for a, b in kinds.items() if b}))

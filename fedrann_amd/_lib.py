@@ -18,7 +18,8 @@ SYMBOLS = (
     "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_set_dedup_mode", "fdr_last_unique", "fdr_kmer_output_scan",
     "fdr_kmer_output_load", "fdr_kmer_search", "fdr_kmer_search_indices", "fdr_kmer_count",
     "fdr_kmer_count_fetch", "fdr_csr_compact", "fdr_host_register", "fdr_host_unregister",
-    "fdr_overlaps_write", "fdr_last_prefilter_launches",
+    "fdr_overlaps_write", "fdr_last_prefilter_launches", "fdr_knn_classes_dev", "fdr_knn_unique_dev",
+    "fdr_knn_expand_dev",
 )
 FDR_MAX_K = 64
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
@@ -80,6 +81,9 @@ def load_library():
     L.fdr_knn_workspace_bytes.argtypes = [vp, i64, i64, i32, i32]
     L.fdr_knn_workspace_bytes.restype = sz
     L.fdr_knn_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, vp, sz, vp]
+    L.fdr_knn_classes_dev.argtypes = [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp, ctypes.POINTER(i32)]
+    L.fdr_knn_unique_dev.argtypes = [vp, i64, i64, vp, vp, vp]
+    L.fdr_knn_expand_dev.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
     L.fdr_last_uncertified.argtypes = [vp]
     L.fdr_set_knn_mode.argtypes = [vp, ctypes.c_int]
     L.fdr_set_dedup_mode.argtypes = [vp, ctypes.c_int]
@@ -377,6 +381,23 @@ class Context:
         self._check(self._L.fdr_knn_dev(self._h, d_Qhat, d_qzero, int(nq), d_That, d_tzero,
                                         int(nt), int(t_base), int(d), int(k), d_idx, d_dist, d_ws,
                                         int(ws_bytes), stream or None), "fdr_knn_dev")
+
+
+    def knn_classes_dev(self, d_That, d_tzero, nt, d, k, nq_max, d_ws, ws_bytes, stream=0):
+        """Duplicate-row classes of the target set for knn_unique_dev / knn_expand_dev; returns the number of
+        unique rows (0: not worth it, use knn_dev)."""
+        nu = ctypes.c_int32()
+        self._check(self._L.fdr_knn_classes_dev(self._h, d_That, d_tzero, int(nt), int(d), int(k), int(nq_max), d_ws,
+                                                int(ws_bytes), stream or None, ctypes.byref(nu)), "fdr_knn_classes_dev")
+        return int(nu.value)
+
+    def knn_unique_dev(self, u_lo, u_hi, d_idx_u, d_dist_u, stream=0):
+        self._check(self._L.fdr_knn_unique_dev(self._h, int(u_lo), int(u_hi), d_idx_u, d_dist_u, stream or None),
+                    "fdr_knn_unique_dev")
+
+    def knn_expand_dev(self, q0, nq, t_base, d_idx_u_all, d_dist_u_all, d_idx, d_dist, stream=0):
+        self._check(self._L.fdr_knn_expand_dev(self._h, int(q0), int(nq), int(t_base), d_idx_u_all, d_dist_u_all,
+                                               d_idx, d_dist, stream or None), "fdr_knn_expand_dev")
 
 
 _default_ctx = None

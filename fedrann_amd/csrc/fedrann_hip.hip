@@ -235,6 +235,17 @@ struct fdr_ctx {
     int last_flagged = 0;  // prefilter mode: queries of the last call that took the exact path
     int last_unique_targets = 0, last_unique_queries = 0;  // duplicate-row classes of the last call
     int last_pass_launches = 0, last_pass_queues = 0;      // prefilter pass of the last call
+    // duplicate-row classes built by fdr_knn_classes_dev for the calls that follow it (fdr_knn_unique_dev /
+    // fdr_knn_expand_dev): the tables live in the caller's workspace
+    struct {
+        bool valid = false;
+        const float *That = nullptr;
+        const uint8_t *tzero = nullptr;
+        int64_t nt = 0, nq_max = 0;
+        int d = 0, k = 0, nu = 0;
+        void *ws = nullptr;
+        size_t ws_bytes = 0;
+    } cls;
     bool timing = false;
     std::vector<hipEvent_t> ev_pool[FDR_NUM_KERNELS];  // start, stop, start, stop, ...
     size_t ev_used[FDR_NUM_KERNELS] = {};
@@ -1023,6 +1034,138 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
 static size_t knn_workspace_bytes_impl(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
     if (knn_dedup_wanted(ctx, nq, nt)) return dedup_layout(ctx, nq, nt, d, k).total;
     return knn_mode_workspace_bytes(ctx, nq, nt, d, k);
+}
+
+// ---- duplicate-row classes across ranks ---------------------------------------------------------
+// A row-sharded run searches a duplicate QUERY row once per rank that holds a member of its class (8 ranks
+// at 1 M reads: 7816 query blocks instead of 6494).  These three calls let the ranks split the UNIQUE rows
+// instead: every rank builds the classes of the (all-gathered) target set -- the same tables on every rank --
+// searches its share of the unique rows, the shares are exchanged (nu x k indices and distances), and every
+// rank expands its own rows from the complete result.
+FDR_EXPORT int fdr_knn_classes_dev(fdr_ctx *ctx, const float *d_That, const uint8_t *d_tzero, int64_t nt, int32_t d,
+                                   int32_t k, int64_t nq_max, void *d_ws, size_t ws_bytes, void *stream,
+                                   int32_t *n_unique_out) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ctx->cls.valid = false;
+    if (!n_unique_out) return fail(FDR_E_ARG, "knn_classes: n_unique_out is null");
+    *n_unique_out = 0;
+    const int dp = fdr_padded_dim(d);
+    if (dp < 0 || k < 1 || k > FDR_MAX_K || nt < k || nq_max <= 0 || nq_max > nt || !d_That || !d_tzero || !d_ws ||
+        nt > 0x7fffffffll)
+        return fail(FDR_E_ARG, "knn_classes: bad argument");
+    if (!knn_dedup_wanted(ctx, nq_max, nt)) return FDR_OK;  // (small sets: the callers use fdr_knn_dev)
+    const DedupLayout L = dedup_layout(ctx, nq_max, nt, d, k);
+    if (ws_bytes < L.total) return fail(FDR_E_ARG, "knn_classes: workspace %zu < required %zu bytes", ws_bytes, L.total);
+    char *ws = static_cast<char *>(d_ws);
+    u64 *hash = (u64 *)(ws + L.off_hash), *hash_s = (u64 *)(ws + L.off_hash_s);
+    int *idx = (int *)(ws + L.off_idx), *idx_s = (int *)(ws + L.off_idx_s), *flag = (int *)(ws + L.off_flag);
+    int *cid = (int *)(ws + L.off_cid), *cls = (int *)(ws + L.off_cls), *cstart = (int *)(ws + L.off_cstart);
+    int *isrep = (int *)(ws + L.off_isrep), *upos = (int *)(ws + L.off_upos), *uofc = (int *)(ws + L.off_uofc);
+    int *cofu = (int *)(ws + L.off_cofu);
+    float *U = (float *)(ws + L.off_U);
+    uint8_t *uzero = (uint8_t *)(ws + L.off_uzero);
+    void *tmp = ws + L.off_tmp;
+    const int n = (int)nt;
+    const unsigned g16 = (unsigned)(((size_t)n * 16 + 255) / 256), g1 = (unsigned)((n + 255) / 256);
+    int trc = timing_begin(ctx, FDR_KERNEL_KNN_DEDUP, st);
+    if (trc) return trc;
+    hipLaunchKernelGGL(hash_rows_kernel, dim3(g16), dim3(256), 0, st, d_That, n, dp, hash, idx);
+    HIP_TRY(hipGetLastError());
+    if (ctx->dedup_mode != FDR_DEDUP_FORCE) {  // (the same probe as launch_knn: enough repeats to pay for the tables?)
+        unsigned tsize = 1024;
+        while (tsize < 2u * (unsigned)n && tsize < (1u << 30)) tsize <<= 1;
+        if ((size_t)tsize * 8 + 256 <= (size_t)nt * dp * 4) {
+            u64 *table = reinterpret_cast<u64 *>(U);
+            int *d_cnt = reinterpret_cast<int *>(table + tsize);
+            HIP_TRY(hipMemsetAsync(table, 0, (size_t)tsize * 8 + 4, st));
+            hipLaunchKernelGGL(dedup_probe_kernel, dim3(g1), dim3(256), 0, st, (const u64 *)hash, n, table, tsize - 1,
+                               d_cnt);
+            HIP_TRY(hipGetLastError());
+            int dups = 0;
+            HIP_TRY(hipMemcpyAsync(&dups, d_cnt, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if ((double)dups < 0.05 * (double)n) return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
+        }
+    }
+    size_t tb = L.tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, hash, hash_s, idx, idx_s, (size_t)n, 0, 64, st));
+    hipLaunchKernelGGL(mark_class_starts_kernel, dim3(g1), dim3(256), 0, st, d_That, n, dp, (const u64 *)hash_s,
+                       (const int *)idx_s, flag);
+    tb = L.tmp_bytes;
+    HIP_TRY(rocprim::inclusive_scan(tmp, tb, flag, cid, (size_t)n, rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(class_tables_kernel, dim3(g1), dim3(256), 0, st, n, (const int *)flag, (const int *)cid,
+                       (const int *)idx_s, cls, cstart, isrep);
+    tb = L.tmp_bytes;
+    HIP_TRY(rocprim::inclusive_scan(tmp, tb, isrep, upos, (size_t)n, rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(unique_tables_kernel, dim3(g1), dim3(256), 0, st, n, (const int *)isrep, (const int *)upos,
+                       (const int *)cls, uofc, cofu);
+    HIP_TRY(hipGetLastError());
+    int nu = 0;
+    HIP_TRY(hipMemcpyAsync(&nu, cid + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (nu < k) return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);  // (fewer unique rows than neighbours asked for)
+    hipLaunchKernelGGL(gather_unique_rows_kernel, dim3(g16), dim3(256), 0, st, d_That, d_tzero, n, dp,
+                       (const int *)isrep, (const int *)upos, U, uzero);
+    HIP_TRY(hipGetLastError());
+    if ((trc = timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st))) return trc;
+    ctx->cls.valid = true;
+    ctx->cls.That = d_That;
+    ctx->cls.tzero = d_tzero;
+    ctx->cls.nt = nt;
+    ctx->cls.nq_max = nq_max;
+    ctx->cls.d = d;
+    ctx->cls.k = k;
+    ctx->cls.nu = nu;
+    ctx->cls.ws = d_ws;
+    ctx->cls.ws_bytes = ws_bytes;
+    ctx->last_unique_targets = nu;
+    *n_unique_out = nu;
+    return FDR_OK;
+}
+
+FDR_EXPORT int fdr_knn_unique_dev(fdr_ctx *ctx, int64_t u_lo, int64_t u_hi, int32_t *d_idx_u, float *d_dist_u,
+                                  void *stream) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (!ctx->cls.valid) return fail(FDR_E_STATE, "knn_unique: no classes (call fdr_knn_classes_dev first)");
+    if (u_lo < 0 || u_hi < u_lo || u_hi > ctx->cls.nu || u_hi - u_lo > ctx->cls.nq_max)
+        return fail(FDR_E_ARG, "knn_unique: bad range [%lld, %lld) of %d unique rows (at most %lld per call)",
+                    (long long)u_lo, (long long)u_hi, ctx->cls.nu, (long long)ctx->cls.nq_max);
+    if (u_hi == u_lo) return FDR_OK;
+    if (!d_idx_u || !d_dist_u) return fail(FDR_E_ARG, "knn_unique: null output");
+    const int dp = fdr_padded_dim(ctx->cls.d);
+    const DedupLayout L = dedup_layout(ctx, ctx->cls.nq_max, ctx->cls.nt, ctx->cls.d, ctx->cls.k);
+    char *ws = static_cast<char *>(ctx->cls.ws);
+    const float *U = (const float *)(ws + L.off_U);
+    const uint8_t *uzero = (const uint8_t *)(ws + L.off_uzero);
+    ctx->last_unique_queries = (int)(u_hi - u_lo);
+    // the unique rows are stored in ascending representative order; a share of them is a block of U
+    return launch_knn_mode(ctx, U + (size_t)u_lo * dp, uzero + u_lo, u_hi - u_lo, U, uzero, ctx->cls.nu, 0, ctx->cls.d,
+                           ctx->cls.k, d_idx_u, d_dist_u, ctx->cls.ws, L.inner_bytes, (hipStream_t)stream);
+}
+
+FDR_EXPORT int fdr_knn_expand_dev(fdr_ctx *ctx, int64_t q0, int64_t nq, int64_t t_base, const int32_t *d_idx_u_all,
+                                  const float *d_dist_u_all, int32_t *d_idx, float *d_dist, void *stream) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (!ctx->cls.valid) return fail(FDR_E_STATE, "knn_expand: no classes (call fdr_knn_classes_dev first)");
+    if (q0 < 0 || nq < 0 || q0 + nq > ctx->cls.nt) return fail(FDR_E_ARG, "knn_expand: bad row range");
+    if (nq == 0) return FDR_OK;
+    if (!d_idx_u_all || !d_dist_u_all || !d_idx || !d_dist) return fail(FDR_E_ARG, "knn_expand: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int k = ctx->cls.k;
+    const DedupLayout L = dedup_layout(ctx, ctx->cls.nq_max, ctx->cls.nt, ctx->cls.d, k);
+    char *ws = static_cast<char *>(ctx->cls.ws);
+    int trc = timing_begin(ctx, FDR_KERNEL_KNN_DEDUP, st);
+    if (trc) return trc;
+    hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)nq), dim3(64), (size_t)k * k * 8, st, (int)q0, (int)nq, k,
+                       (int)t_base, (const int *)(ws + L.off_cls), (const int *)(ws + L.off_uofc), (const int *)nullptr,
+                       (const int *)d_idx_u_all, d_dist_u_all, (const int *)(ws + L.off_cofu),
+                       (const int *)(ws + L.off_cstart), (const int *)(ws + L.off_idx_s), d_idx, d_dist);
+    HIP_TRY(hipGetLastError());
+    return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
 }
 
 // ---- device-pointer API ----------------------------------------------------------------------

@@ -3,7 +3,9 @@
 The path shards by read rows: rank g embeds and normalises rows [g*S, (g+1)*S) of the feature
 matrix, the normalised embeddings (and their zero-row flags) are exchanged with ONE all-gather
 (RCCL over xGMI when the process group's backend is "nccl"), and each rank then searches its own
-rows against all N targets.  No merge step: a query's full top-k is produced on its owner rank.
+rows against all N targets.  No merge step: a query's full top-k is produced on its owner rank.  When the
+gathered rows repeat (>= 5 % duplicates; the sparse projections of overlapping reads often coincide), the
+ranks split the UNIQUE rows instead and exchange those results with a second, small all-gather (see step()).
 
 torch is used for device memory, streams and torch.distributed only; the arithmetic is in
 libfedrann_hip.so (HipEngine).  The engine is injected so that the sharding / exchange logic can be
@@ -66,6 +68,28 @@ class HipEngine:
                          self._ws.numel(), self._stream())
         return idx, dst
 
+    # -- duplicate-row classes across ranks (fdr_knn_classes_dev / _unique_dev / _expand_dev) --------------
+    def knn_classes(self, That, tzero, nt, d, k, nq_max):
+        """Build the classes of the gathered target set; returns the number of unique rows, 0 = use knn()."""
+        need = self.ctx.knn_workspace_bytes(nq_max, nt, d, k)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.ctx.knn_classes_dev(That.data_ptr(), tzero.data_ptr(), nt, d, k, nq_max, self._ws.data_ptr(),
+                                        self._ws.numel(), self._stream())
+
+    def knn_unique(self, u_lo, u_hi, k, out_idx, out_dst):
+        """k-NN of the unique rows [u_lo, u_hi) into the first u_hi - u_lo rows of out_idx / out_dst."""
+        if u_hi > u_lo:
+            self.ctx.knn_unique_dev(u_lo, u_hi, out_idx.data_ptr(), out_dst.data_ptr(), self._stream())
+
+    def knn_expand(self, q0, nq, k, idx_u_all, dst_u_all):
+        idx = torch.empty((nq, k), dtype=torch.int32, device=self.device)
+        dst = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        if nq:
+            self.ctx.knn_expand_dev(q0, nq, 0, idx_u_all.data_ptr(), dst_u_all.data_ptr(), idx.data_ptr(),
+                                    dst.data_ptr(), self._stream())
+        return idx, dst
+
 
 class ShardedPipeline:
     """embed -> normalise -> all-gather -> k-NN for this rank's row block."""
@@ -86,6 +110,7 @@ class ShardedPipeline:
             self.zero_loc = torch.zeros((S,), dtype=torch.uint8, device=self.device)
         else:
             self.Ehat_loc, self.zero_loc = self.Ehat_all, self.zero_all
+        self._iu = self._du = self._iu_loc = self._du_loc = None  # unique-row results (sized on first use)
 
     def step(self, indptr_local, indices_local):
         """indptr_local / indices_local: this rank's CSR rows (indptr rebased to 0) as tensors on
@@ -97,6 +122,26 @@ class ShardedPipeline:
             dist.all_gather_into_tensor(self.Ehat_all, self.Ehat_loc, group=self.group)
             dist.all_gather_into_tensor(self.zero_all, self.zero_loc, group=self.group)
         q0 = self.rank * self.S
+        if self.world > 1 and hasattr(self.engine, "knn_classes"):
+            # Split the UNIQUE rows over the ranks instead of searching every duplicate query row on every
+            # rank that holds a member of its class: all ranks build the same class tables from the gathered
+            # rows, each searches its share of the unique rows, one more all-gather exchanges the shares
+            # (nu x k indices + distances), and each rank expands its own rows.
+            nq_max = -(-self.n // self.world)
+            nu = self.engine.knn_classes(self.Ehat_all, self.zero_all, self.n, self.d, self.k, nq_max)
+            if nu > 0:
+                Su = -(-nu // self.world)
+                u_lo, u_hi = min(nu, self.rank * Su), min(nu, (self.rank + 1) * Su)
+                if self._iu is None or self._iu.shape[0] != Su * self.world:
+                    self._iu = torch.zeros((Su * self.world, self.k), dtype=torch.int32, device=self.device)
+                    self._du = torch.zeros((Su * self.world, self.k), dtype=torch.float32, device=self.device)
+                    self._iu_loc = torch.zeros((Su, self.k), dtype=torch.int32, device=self.device)
+                    self._du_loc = torch.zeros((Su, self.k), dtype=torch.float32, device=self.device)
+                self.engine.knn_unique(u_lo, u_hi, self.k, self._iu_loc, self._du_loc)
+                dist.all_gather_into_tensor(self._iu, self._iu_loc, group=self.group)
+                dist.all_gather_into_tensor(self._du, self._du_loc, group=self.group)
+                idx, dst = self.engine.knn_expand(q0, nloc, self.k, self._iu, self._du)  # (unique row u sits at row u)
+                return idx, dst, E
         idx, dst = self.engine.knn(self.Ehat_all[q0:q0 + nloc], self.zero_all[q0:q0 + nloc], nloc,
                                    self.Ehat_all, self.zero_all, self.n, self.d, self.k)
         return idx, dst, E

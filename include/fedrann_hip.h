@@ -123,6 +123,25 @@ int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64
                 const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int32_t d,
                 int32_t k, int32_t *d_idx, float *d_dist, void *d_workspace, size_t workspace_bytes,
                 void *stream);
+/* ---- duplicate-row classes across the ranks of a row-sharded run -----------------------------------
+ * fdr_knn_dev searches a duplicate QUERY row once per rank that holds a member of its class.  With these
+ * three calls the ranks split the UNIQUE rows instead (same results):
+ *   fdr_knn_classes_dev  builds the classes of the target set (the all-gathered Ehat: the same tables on
+ *                        every rank) in the workspace -- fdr_knn_workspace_bytes(ctx, nq_max, nt, d, k) bytes,
+ *                        nq_max = the most unique rows one later call will search -- and returns their number
+ *                        in *n_unique_out; 0 = not worth it (small set, < 5 % repeats): use fdr_knn_dev.
+ *   fdr_knn_unique_dev   k-NN of the unique rows [u_lo, u_hi) (ascending representative order) against all
+ *                        unique rows: d_idx_u int32 [u_hi - u_lo, k] (unique-row numbers), d_dist_u float32.
+ *   fdr_knn_expand_dev   given the results of ALL unique rows (the ranks' shares concatenated: [n_unique, k]),
+ *                        the neighbours of the original rows [q0, q0 + nq): d_idx (+ t_base), d_dist [nq, k].
+ * The workspace must stay untouched between the three calls; fdr_knn_classes_dev synchronises the stream. */
+int fdr_knn_classes_dev(fdr_ctx *ctx, const float *d_That, const uint8_t *d_tzero, int64_t nt, int32_t d, int32_t k,
+                        int64_t nq_max, void *d_workspace, size_t workspace_bytes, void *stream,
+                        int32_t *n_unique_out);
+int fdr_knn_unique_dev(fdr_ctx *ctx, int64_t u_lo, int64_t u_hi, int32_t *d_idx_u, float *d_dist_u, void *stream);
+int fdr_knn_expand_dev(fdr_ctx *ctx, int64_t q0, int64_t nq, int64_t t_base, const int32_t *d_idx_u_all,
+                       const float *d_dist_u_all, int32_t *d_idx, float *d_dist, void *stream);
+
 /* ---- per-kernel timing (bench.py's roofline figures) -----------------------------------------
  * With timing enabled every kernel launch is bracketed by its own hipEvent pair recorded on the
  * stream the kernel is launched on.  fdr_timing_read() waits for the recorded launches of one kernel

@@ -48,3 +48,36 @@ def test_sharded_pipeline_on_gpu_matches_oracle(tmp_path, oracle, world, R, d, k
         assert np.array_equal(z["idx"], wi[lo:hi])
         assert np.array_equal(z["dist"].view(np.uint32), wd[lo:hi].view(np.uint32))
     assert rows == E.shape[0]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_unique_row_split(tmp_path, oracle, world):
+    """Duplicate-heavy rows (classes of 1 .. thousands of members, incl. the all-zero class): the ranks build
+    the same class tables from the gathered rows, split the UNIQUE rows, exchange those results and expand
+    their own rows -- bit-identical to the unsharded oracle, and no rank searched more than its share."""
+    from test_gpu_parity import _rows_with_duplicate_classes
+    n, d, k = 40_001, 128, 20
+    E = _rows_with_duplicate_classes(np.random.default_rng(5), n, d, 6000)
+    path = tmp_path / "E.npy"
+    np.save(path, E)
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gpu_rank_worker_dup.py"), str(tmp_path),
+                                       str(path), str(k)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    wi, wd = oracle.knn(E, k)
+    rows = 0
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        lo, hi = int(z["lo"]), int(z["hi"])
+        assert lo == rows
+        rows = hi
+        assert np.array_equal(z["idx"], wi[lo:hi])
+        assert np.array_equal(z["dist"].view(np.uint32), wd[lo:hi].view(np.uint32))
+        nu, nuq = int(z["unique_targets"]), int(z["unique_queries"])
+        assert k <= nu < n // 2 and nuq <= -(-nu // world)  # the split engaged: a share of the unique rows
+    assert rows == n
