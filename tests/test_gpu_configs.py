@@ -79,6 +79,8 @@ def test_config4_one_rank_share_10m_targets(ctx, oracle):
     E = _device_embeddings(10_000_000, 128, nnz=6, loci=4_000_000, seed=4)
     ut, uq = _check_rank_share(ctx, oracle, E, 1_250_000, 20)
     assert 20 <= ut <= 10_000_000 and uq <= 1_250_000
+    launches, queues = ctx.last_prefilter_launches()
+    assert queues == 2 and launches > 100  # synchronised rounds of two workgroups per CU on two queues
 
 
 def test_config5_shape_doubled_rows_d256_k50(ctx, oracle):
@@ -89,6 +91,16 @@ def test_config5_shape_doubled_rows_d256_k50(ctx, oracle):
     E = _device_embeddings(1_000_000, 256, nnz=8, loci=300_000, seed=5, doubling=True)
     _check_rank_share(ctx, oracle, E, 125_000, 50)
     _check_rank_share(ctx, oracle, E[:200_000].contiguous(), 200_000, 50, sample=128)  # and all-pairs at 200 k rows
+
+
+def test_reference_default_dimension_500_in_rounds(ctx, oracle):
+    """d = 500 (the reference's default -n; DP = 512 kernels, two workgroups per CU), k = 50, enough query blocks
+    for the prefilter pass to run in synchronised rounds on two queues: a rank's quarter of 600 k rows."""
+    ctx.set_knn_mode("auto")
+    ctx.set_dedup_mode("auto")
+    E = _device_embeddings(600_000, 500, nnz=8, loci=250_000, seed=6)
+    _check_rank_share(ctx, oracle, E, 150_000, 50, sample=128)
+    assert ctx.last_prefilter_launches()[1] == 2
 
 
 def test_per_rank_workspace_of_configs_4_and_5_fits_hbm(ctx):
