@@ -1191,6 +1191,7 @@ FDR_EXPORT int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_q
                            size_t workspace_bytes, void *stream) {
     int rc = use_device(ctx);
     if (rc) return rc;
+    if (d_workspace == ctx->cls.ws) ctx->cls.valid = false;  // (this call overwrites the tables fdr_knn_classes_dev left there)
     return launch_knn(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
                       d_workspace, workspace_bytes, (hipStream_t)stream);
 }
