@@ -324,7 +324,10 @@ FDR_EXPORT int fdr_destroy(fdr_ctx *ctx) {
         for (hipEvent_t e : ctx->ev_pool[i]) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     for (hipStream_t a : ctx->aux_stream)
-        if (a) (void)hipStreamDestroy(a);
+        if (a) {
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamDestroy(a);
+        }
     for (hipEvent_t e : ctx->aux_ev)
         if (e) (void)hipEventDestroy(e);
     delete ctx;
