@@ -16,7 +16,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = _lib.Context(0)
 bad = 0
 for c in range(cases):
-    n = int(rng.choice([9000, 17000, 33000, 70000]))
+    n = int(rng.choice([9000, 17000, 33000, 70000, 150000, 300000]))  # (>= 131073 rows: synchronised rounds, two queues)
     d = int(rng.choice([64, 128, 128, 200, 256, 500]))
     k = int(rng.choice([5, 20, 20, 33, 50, 56, 64]))
     kind = int(rng.integers(0, 4))
@@ -34,10 +34,12 @@ for c in range(cases):
         E = rng.integers(-1, 2, size=(n, d)).astype(np.float32)
         E[rng.random(E.shape) < 0.9] = 0
     t0 = time.perf_counter()
-    os.environ["FDR_KNN_MODE"] = "prefilter"
+    ctx.set_dedup_mode(str(rng.choice(["auto", "auto", "off", "force"])))
+    ctx.set_knn_mode("prefilter")
     pi, pd = ctx.knn(E, k)
     unc, uniq = ctx.last_uncertified(), ctx.last_unique()
-    os.environ["FDR_KNN_MODE"] = "exact"
+    launches = ctx.last_prefilter_launches()
+    ctx.set_knn_mode("exact")
     xi, xd = ctx.knn(E, k)
     same = np.array_equal(pi, xi) and np.array_equal(pd.view(np.uint32), xd.view(np.uint32))
     note = ""
@@ -47,7 +49,7 @@ for c in range(cases):
         same = same and ok
         note = " oracle=%s" % ok
     bad += not same
-    print("case %2d n=%6d d=%3d k=%2d kind=%d uncertified=%6d unique=%s  %s%s  %.1fs"
-          % (c, n, d, k, kind, unc, uniq, "OK" if same else "MISMATCH", note, time.perf_counter() - t0), flush=True)
+    print("case %2d n=%6d d=%3d k=%2d kind=%d uncertified=%6d unique=%s launches=%s  %s%s  %.1fs"
+          % (c, n, d, k, kind, unc, uniq, launches, "OK" if same else "MISMATCH", note, time.perf_counter() - t0), flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
