@@ -519,17 +519,20 @@ struct PrefilterLayout {
     size_t off_ht, off_hq, off_cand, off_counter, off_flagged, off_qc, off_qzc, off_idxc, off_distc;
     size_t off_rlist, off_theta, off_hqc, off_thetac, off_cnt, off_rcand, total;  // range pass
     int rchunk;
+    int sym;  // symmetric pass planned: threshold table, inbox counts, inboxes, the log and its chunk table
+    size_t off_gthr, off_icnt, off_inbox, off_alloc, off_fill, off_erow, off_ekey;
+    unsigned e_cap;
 };
 
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
+static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k, bool sym = false) {
     PrefilterLayout L;
     L.kp = (k + prefilter_extra() + 1) & ~1;
     L.chunk = (int)std::min<int64_t>(nq, 16384);
     const size_t exact_all = knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
     const int dp = fdr_padded_dim(d);
-    const KnnPlan pp = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp));
+    const KnnPlan pp = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp), sym && nq == nt);
     // (a later call on fewer unique rows may plan more, shorter segments: room for the largest such plan)
     const size_t pre = std::max(pp.total_bytes, pp.bits_bytes + pp.shared_bytes +
                                                     prefilter_partial_bound(nq, nt, L.kp, pp.qw));
@@ -554,6 +557,20 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.off_thetac = o;   o += align256((size_t)L.rchunk * 4);
     L.off_cnt = o;      o += align256((size_t)L.rchunk * 4);
     L.off_rcand = o;    o += align256((size_t)L.rchunk * RANGE_CAP * 4);
+    L.sym = pp.sym;
+    L.off_gthr = L.off_icnt = L.off_inbox = L.off_alloc = L.off_fill = L.off_erow = L.off_ekey = 0;
+    L.e_cap = 0;
+    if (L.sym) {
+        L.off_gthr = o;   o += align256((size_t)((nt + 31) / 32) * 16);
+        L.off_icnt = o;   o += align256((size_t)nt * 4);
+        L.off_inbox = o;  o += align256((size_t)nt * SYM_INBOX_CAP * 8);
+        const size_t per_row = (size_t)std::max(64, dev_env_int("FDR_KNN_SYM_LOG", 512));  // log entries per row
+        L.e_cap = (unsigned)std::min<size_t>((size_t)0xffff0000u, ((size_t)nt * per_row + SYM_CHUNK - 1) / SYM_CHUNK * SYM_CHUNK);
+        L.off_alloc = o;  o += 256;
+        L.off_fill = o;   o += align256((size_t)(L.e_cap / SYM_CHUNK) * 4);
+        L.off_erow = o;   o += align256((size_t)L.e_cap * 4);
+        L.off_ekey = o;   o += align256((size_t)L.e_cap * 8);
+    }
     L.total = o;
     return L;
 }
@@ -634,13 +651,16 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
 static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
                                 const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base,
                                 int d, int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes,
-                                hipStream_t st) {
-    const PrefilterLayout L = prefilter_layout(ctx, nq, nt, d, k);
+                                hipStream_t st, bool allow_sym = true) {
+    // the queries ARE the targets (row i of one is row i of the other): the symmetric pass applies
+    const bool self = d_Qhat == d_That && d_qzero == d_tzero && nq == nt;
+    PrefilterLayout L = prefilter_layout(ctx, nq, nt, d, k, self && allow_sym);
+    if (L.sym && ws_bytes < L.total) L = prefilter_layout(ctx, nq, nt, d, k, false);  // (a workspace sized for more queries than targets)
     if (ws_bytes < L.total)
         return fail(FDR_E_ARG, "knn: workspace %zu < required %zu bytes", ws_bytes, L.total);
     char *ws = static_cast<char *>(d_ws);
     _Float16 *d_ht = reinterpret_cast<_Float16 *>(ws + L.off_ht);
-    _Float16 *d_hq = reinterpret_cast<_Float16 *>(ws + L.off_hq);
+    _Float16 *d_hq = self ? d_ht : reinterpret_cast<_Float16 *>(ws + L.off_hq);
     u64 *d_cand = reinterpret_cast<u64 *>(ws + L.off_cand);
     int *d_counter = reinterpret_cast<int *>(ws + L.off_counter);
     int *d_flagged = reinterpret_cast<int *>(ws + L.off_flagged);
@@ -652,7 +672,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
 
     const int dp = fdr_padded_dim(d);
     const int pshape = prefilter_shape(dp, kp);
-    const KnnPlan p = knn_plan(ctx->num_cus, nq, nt, d, kp, pshape);
+    const KnnPlan p = knn_plan(ctx->num_cus, nq, nt, d, kp, pshape, L.sym != 0);
     const KnnShape &sh = kShapes[pshape];
     unsigned *d_bits = reinterpret_cast<unsigned *>(ws);
     unsigned *d_shared = reinterpret_cast<unsigned *>(ws + p.bits_bytes);
@@ -662,8 +682,26 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if (trc) return trc;
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nt * (dp / 8) + 255) / 256)), dim3(256), 0, st, d_That,
                        (long long)nt * (dp / 8), d_ht);
-    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nq * (dp / 8) + 255) / 256)), dim3(256), 0, st, d_Qhat,
-                       (long long)nq * (dp / 8), d_hq);
+    if (!self)
+        hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nq * (dp / 8) + 255) / 256)), dim3(256), 0, st, d_Qhat,
+                           (long long)nq * (dp / 8), d_hq);
+    SymArgs sym = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 1, 1};
+    int *d_icnt = nullptr;
+    u64 *d_inbox = nullptr;
+    if (p.sym) {
+        sym.gthr = reinterpret_cast<const int *>(ws + L.off_gthr);
+        sym.alloc = reinterpret_cast<unsigned *>(ws + L.off_alloc);
+        sym.fill = reinterpret_cast<int *>(ws + L.off_fill);
+        sym.e_row = reinterpret_cast<unsigned *>(ws + L.off_erow);
+        sym.e_key = reinterpret_cast<u64 *>(ws + L.off_ekey);
+        sym.e_cap = L.e_cap;
+        sym.seg_rows = p.segs.b[1] - p.segs.b[0];
+        sym.nseg = p.nseg;
+        d_icnt = reinterpret_cast<int *>(ws + L.off_icnt);
+        d_inbox = reinterpret_cast<u64 *>(ws + L.off_inbox);
+        HIP_TRY(hipMemsetAsync(d_icnt, 0, (size_t)nt * 4, st));
+        HIP_TRY(hipMemsetAsync(sym.alloc, 0, 256, st));
+    }
     hipLaunchKernelGGL(pack_zero_bits_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st,
                        d_tzero, (int)nt, d_bits, d_shared, p.nq_pad);
     HIP_TRY(hipGetLastError());
@@ -679,20 +717,18 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
         // then starts warm -- what a perfect pre-pass could buy
         hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)(p.nqb * p.nseg)),
                            dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad,
-                           d_partial, d_shared, ib, 0, p.nqb FDR_DBG_ARG(0));
+                           d_partial, d_shared, ib, 0, p.nqb, sym FDR_DBG_ARG(0));
     }
 #endif
     const int pdbg = dev_env_int("FDR_KNN_DEBUG", 0);
     (void)pdbg;
-    // the nqb * nseg work items in launches of p.cohort workgroups (0: one launch): see knn_plan_compute
-    const long long n_items = (long long)p.nqb * p.nseg;
+    // the nqb * nslot work items in launches of p.cohort workgroups (0: one launch): see knn_plan_compute
+    const long long n_items = (long long)p.nqb * p.nslot;
     const long long per_launch = p.cohort > 0 ? p.cohort : n_items;
     // Several queues: with the launches of the synchronised rounds dealt round-robin to the caller's stream and
     // further ones, the workgroups of a later launch take the slots the stragglers of an earlier one have
     // freed (one queue: every launch ends with its slowest workgroup while the rest of the chip idles).
     const int nqueues = p.cohort > 0 && n_items > per_launch ? std::max(1, std::min(p.queues, 4)) : 1;
-    ctx->last_pass_launches = (int)((n_items + per_launch - 1) / per_launch);
-    ctx->last_pass_queues = nqueues;
     // one timed span for the whole pass when launches overlap (their own spans would count the same time twice)
     if (nqueues > 1 && (trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
     hipStream_t qs[4] = {st, st, st, st};
@@ -701,31 +737,67 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             for (hipStream_t &a : ctx->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
             for (hipEvent_t &e : ctx->aux_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        HIP_TRY(hipEventRecord(ctx->aux_ev[0], st));  // the pass's inputs are ready on `st`
-        for (int q = 1; q < nqueues; ++q) {
-            qs[q] = ctx->aux_stream[q - 1];
-            HIP_TRY(hipStreamWaitEvent(qs[q], ctx->aux_ev[0], 0));
-        }
+        for (int q = 1; q < nqueues; ++q) qs[q] = ctx->aux_stream[q - 1];
     }
+    auto fork = [&]() -> int {  // what `st` has queued so far is visible to the other queues' next launches
+        if (nqueues > 1) {
+            HIP_TRY(hipEventRecord(ctx->aux_ev[0], st));
+            for (int q = 1; q < nqueues; ++q) HIP_TRY(hipStreamWaitEvent(qs[q], ctx->aux_ev[0], 0));
+        }
+        return FDR_OK;
+    };
+    auto join = [&]() -> int {  // `st` waits for everything the other queues have been given
+        for (int q = 1; q < nqueues; ++q) {
+            HIP_TRY(hipEventRecord(ctx->aux_ev[q], qs[q]));
+            HIP_TRY(hipStreamWaitEvent(st, ctx->aux_ev[q], 0));
+        }
+        return FDR_OK;
+    };
+    int li = 0;  // launches so far (launch li goes to queue li % nqueues)
+    auto launch_items = [&](long long it_lo, long long it_hi) -> int {
 #define FDR_LAUNCH_PRE3(KERNEL_, THREADS_)                                                              \
     do {                                                                                                \
-        int li_ = 0;                                                                                    \
-        for (long long base_ = 0; base_ < n_items; base_ += per_launch, ++li_) { /* (every launch its own timed span) */ \
-            hipStream_t ls_ = qs[li_ % nqueues];                                                        \
+        for (long long base_ = it_lo; base_ < it_hi; base_ += per_launch, ++li) { /* (one queue: every launch its own timed span) */ \
+            hipStream_t ls_ = qs[li % nqueues];                                                         \
             if (nqueues == 1 && (trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, ls_))) return trc;   \
-            hipLaunchKernelGGL(KERNEL_, dim3((unsigned)std::min(per_launch, n_items - base_)), dim3(THREADS_), lds, \
+            hipLaunchKernelGGL(KERNEL_, dim3((unsigned)std::min(per_launch, it_hi - base_)), dim3(THREADS_), lds, \
                                ls_, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, \
-                               d_shared, ib, (int)base_, p.nqb FDR_DBG_ARG(pdbg));                       \
+                               d_shared, ib, (int)base_, p.nqb, sym FDR_DBG_ARG(pdbg));                  \
             if (nqueues == 1 && (trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, ls_))) return trc;     \
         }                                                                                               \
     } while (0)
+#ifdef FDR_DEV  /* (the symmetric pass exists in development builds only: measured slower) */
+#define FDR_LAUNCH_SYM(KERNEL_, THREADS_) if (p.sym) FDR_LAUNCH_PRE3(KERNEL_, THREADS_); else
+#else
+#define FDR_LAUNCH_SYM(KERNEL_, THREADS_)
+#endif
 #define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_) /* (the ring is at most 32 KB: no dynamic-LDS attribute) */ \
-    FDR_LAUNCH_PRE3((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>), 64 * NW_)
+    do {                                                                                                \
+        FDR_LAUNCH_SYM((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_, false, true>), 64 * NW_)     \
+        FDR_LAUNCH_PRE3((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>), 64 * NW_);                \
+    } while (0)
 #define FDR_LAUNCH_PRE(DP_, NQ_, NW_, WPS_, U_)                                                         \
     do {                                                                                                \
         if (kp <= 32) FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 16);                                     \
         else FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 32);                                              \
     } while (0)
+        if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_PAIR", 1) != 0) {
+            // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
+            // <= 128 VGPRs.  FDR_KNN_PAIR=0: development knob, one chain)
+            FDR_LAUNCH_SYM((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true, true>), 256)
+            FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
+        } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
+        else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
+        else FDR_LAUNCH_PRE(512, 1, 4, 2, 2);
+#undef FDR_LAUNCH_PRE3
+#undef FDR_LAUNCH_PRE2
+#undef FDR_LAUNCH_PRE
+#undef FDR_LAUNCH_SYM
+        HIP_TRY(hipGetLastError());
+        return FDR_OK;
+    };
+    int lrc;
+    if ((lrc = fork())) return lrc;
 #ifdef FDR_DEV
     if (pshape == FDR_SHAPE_PREFILTER2) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter2_kernel<16>),
@@ -735,23 +807,36 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                            d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, d_shared,
                            ib FDR_DBG_ARG(pdbg));
         if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
+        li = 1;
     } else
 #endif
-    if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_PAIR", 1) != 0) {
-        // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
-        // <= 128 VGPRs.  FDR_KNN_PAIR=0: development knob, one chain)
-        FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
-    } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
-    else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
-    else FDR_LAUNCH_PRE(512, 1, 4, 2, 2);
-#undef FDR_LAUNCH_PRE3
-#undef FDR_LAUNCH_PRE2
-#undef FDR_LAUNCH_PRE
-    HIP_TRY(hipGetLastError());
-    for (int q = 1; q < nqueues; ++q) {  // the merge below (on `st`) needs the other queues' launches too
-        HIP_TRY(hipEventRecord(ctx->aux_ev[q], qs[q]));
-        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_ev[q], 0));
+    if (!p.sym) {
+        if ((lrc = launch_items(0, n_items))) return lrc;
+    } else {
+        // symmetric pass, slot-major: slot 0 (every query block against its own segment) gives every row a bound;
+        // then the table of group thresholds the other side's test reads is made from the bounds (complete for
+        // slot 0: both queues are joined once) and refreshed after every further slot's launches WITHOUT
+        // waiting for the other queue -- an older table is only looser (see sym_group_thresholds_kernel)
+        const int ngroups = (int)((nt + 31) / 32) * 4;
+        const int refresh = dev_env_int("FDR_KNN_SYM_REFRESH", 1);  // development knob: 0 = only after slot 0, 2 = joined
+        for (int slot = 0; slot < p.nslot; ++slot) {
+            if ((lrc = launch_items((long long)slot * p.nqb, (long long)(slot + 1) * p.nqb))) return lrc;
+            if (slot + 1 == p.nslot || (slot > 0 && refresh == 0)) continue;
+            if (slot == 0 || refresh == 2) {
+                if ((lrc = join())) return lrc;
+            }
+            hipLaunchKernelGGL(sym_group_thresholds_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st,
+                               (const unsigned *)d_shared, (int)nt, ib, const_cast<int *>(sym.gthr), ngroups,
+                               refresh == 3 ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+            if (slot == 0 || refresh == 2) {
+                if ((lrc = fork())) return lrc;
+            }
+        }
     }
+    ctx->last_pass_launches = li;
+    ctx->last_pass_queues = nqueues;
+    if ((lrc = join())) return lrc;  // the merge below (on `st`) needs the other queues' launches too
     if (nqueues > 1 && (trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
 #ifdef FDR_DEBUG_COUNTERS
     if (pdbg & 2) {
@@ -766,8 +851,28 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
 #endif
 
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
+    if (p.sym) {
+        hipLaunchKernelGGL(sym_scatter_kernel, dim3(L.e_cap / SYM_CHUNK), dim3(SYM_CHUNK), 0, st,
+                           (const unsigned *)sym.alloc, (const int *)sym.fill, (const unsigned *)sym.e_row,
+                           (const u64 *)sym.e_key, (const unsigned *)d_shared, ib, (int)t_base, d_icnt, d_inbox,
+                           SYM_INBOX_CAP);
+        HIP_TRY(hipGetLastError());
+        if (dev_env_int("FDR_KNN_DEBUG", 0) & 32) {  // (development: log and inbox volumes)
+            unsigned al[2];
+            HIP_TRY(hipMemcpyAsync(al, sym.alloc, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            std::vector<int> hc((size_t)nt);
+            HIP_TRY(hipMemcpy(hc.data(), d_icnt, (size_t)nt * 4, hipMemcpyDeviceToHost));
+            long long tot = 0, over = 0;
+            int mx = 0;
+            for (int v : hc) { tot += v; over += v > SYM_INBOX_CAP; mx = std::max(mx, v); }
+            fprintf(stderr, "[fdr sym] log entries handed out %u of %u (overflow %u), inbox entries %lld (%.1f per row, max %d, rows over %d: %lld)\n",
+                    al[0], L.e_cap, al[1], tot, (double)tot / (double)nt, mx, SYM_INBOX_CAP, over);
+        }
+    }
     hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
-                       (const u64 *)d_partial, p.nseg, (int)nq, p.nq_pad, kp, d_cand);
+                       (const u64 *)d_partial, p.nslot, (int)nq, p.nq_pad, kp, d_cand, (const int *)d_icnt,
+                       (const u64 *)d_inbox, SYM_INBOX_CAP);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(d_counter, 0, 16, st));
     int *d_rlist = reinterpret_cast<int *>(ws + L.off_rlist);
@@ -792,8 +897,13 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     // how many queries could not be certified / are all-zero / need a range pass?  (one 12-byte
     // read-back; the passes below are sized from it)
     int counts[3] = {0, 0, 0};
+    unsigned log_state[2] = {0u, 0u};
     HIP_TRY(hipMemcpyAsync(counts, d_counter, 12, hipMemcpyDeviceToHost, st));
+    if (p.sym) HIP_TRY(hipMemcpyAsync(log_state, sym.alloc, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (log_state[1] != 0u)  // the symmetric pass's log overflowed (never seen): the plain pass instead
+        return launch_knn_prefilter(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist, d_ws,
+                                    ws_bytes, st, false);
     int count = counts[0];
     const int zcount = counts[1], rcount = counts[2];
     ctx->last_flagged = count + rcount;
@@ -852,7 +962,11 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
 }
 
 static size_t knn_mode_workspace_bytes(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
-    if (knn_prefilter_wanted(ctx, fdr_padded_dim(d), nt, k)) return prefilter_layout(ctx, nq, nt, d, k).total;
+    if (knn_prefilter_wanted(ctx, fdr_padded_dim(d), nt, k)) {
+        const size_t plain = prefilter_layout(ctx, nq, nt, d, k).total;
+        // (as many queries as targets: they may BE the targets -- room for the symmetric pass's inboxes)
+        return nq == nt ? std::max(plain, prefilter_layout(ctx, nq, nt, d, k, true).total) : plain;
+    }
     return knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
 }
 
@@ -1016,14 +1130,19 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     }
     hipLaunchKernelGGL(gather_unique_rows_kernel, dim3(g16), dim3(256), 0, st, d_That, d_tzero, n, dp,
                        (const int *)isrep, (const int *)upos, U, uzero);
-    hipLaunchKernelGGL(gather_unique_queries_kernel, dim3((unsigned)(((size_t)nu * 16 + 255) / 256)), dim3(256),
-                       0, st, (const float *)U, (const unsigned char *)uzero, nu, dp, (const int *)uqflag,
-                       (const int *)uqpos, Uq, uqz);
+    if (nuq != nu)  // (else the unique queries are the unique rows: no copy, see below)
+        hipLaunchKernelGGL(gather_unique_queries_kernel, dim3((unsigned)(((size_t)nu * 16 + 255) / 256)), dim3(256),
+                           0, st, (const float *)U, (const unsigned char *)uzero, nu, dp, (const int *)uqflag,
+                           (const int *)uqpos, Uq, uqz);
     HIP_TRY(hipGetLastError());
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st))) return trc;
     // unique rows are stored in ascending representative order, and the unique queries are a subsequence
     // of them; the inner search numbers targets 0..nu-1
-    int rc = launch_knn_mode(ctx, Uq, uqz, nuq, U, uzero, nu, 0, d, k, idx_u, dist_u, d_ws, L.inner_bytes, st);
+    // (every unique row is a query: Uq would be a copy of U -- the same pointers let the prefilter mode see that
+    // the queries are the targets)
+    const bool all_q = nuq == nu;
+    int rc = launch_knn_mode(ctx, all_q ? U : Uq, all_q ? uzero : uqz, nuq, U, uzero, nu, 0, d, k, idx_u, dist_u, d_ws,
+                             L.inner_bytes, st);
     if (rc) return rc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_DEDUP, st))) return trc;
     hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)nq), dim3(64), (size_t)k * k * 8, st, q0, (int)nq, k, (int)t_base,
