@@ -49,6 +49,11 @@ for c in range(cases):
         same = same and ok
         note = " oracle=%s" % ok
     bad += not same
+    if not np.array_equal(pi, xi) or not np.array_equal(pd.view(np.uint32), xd.view(np.uint32)):
+        rows = np.flatnonzero((pi != xi).any(1) | (pd.view(np.uint32) != xd.view(np.uint32)).any(1))
+        print("   prefilter != exact in %d rows, first %s" % (rows.size, rows[:5]))
+        for r in rows[:2]:
+            print("   row", r, "nnz", int((E[r] != 0).sum()), "\n    P", pi[r], pd[r], "\n    X", xi[r], xd[r])
     print("case %2d n=%6d d=%3d k=%2d kind=%d uncertified=%6d unique=%s launches=%s  %s%s  %.1fs"
           % (c, n, d, k, kind, unc, uniq, launches, "OK" if same else "MISMATCH", note, time.perf_counter() - t0), flush=True)
 print("mismatches:", bad)
