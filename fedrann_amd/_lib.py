@@ -17,7 +17,7 @@ SYMBOLS = (
     "fdr_normalize_dev", "fdr_knn_workspace_bytes", "fdr_knn_dev", "fdr_timing", "fdr_timing_read",
     "fdr_last_uncertified", "fdr_set_knn_mode", "fdr_set_dedup_mode", "fdr_last_unique", "fdr_kmer_output_scan",
     "fdr_kmer_output_load", "fdr_kmer_search", "fdr_kmer_search_indices", "fdr_kmer_count",
-    "fdr_kmer_count_fetch", "fdr_csr_compact", "fdr_host_register", "fdr_host_unregister",
+    "fdr_kmer_count_fetch", "fdr_set_kmer_count_block", "fdr_last_kmer_count_blocks", "fdr_csr_compact", "fdr_host_register", "fdr_host_unregister",
     "fdr_overlaps_write", "fdr_last_prefilter_launches", "fdr_knn_classes_dev", "fdr_knn_unique_dev",
     "fdr_knn_expand_dev",
 )
@@ -100,6 +100,8 @@ def load_library():
     L.fdr_kmer_search_indices.argtypes = [vp, vp]
     L.fdr_kmer_count.argtypes = [vp, vp, vp, i64, i32, i64, p64]
     L.fdr_kmer_count_fetch.argtypes = [vp, vp, vp]
+    L.fdr_set_kmer_count_block.argtypes = [vp, ctypes.c_int64]
+    L.fdr_last_kmer_count_blocks.argtypes = [vp]
     L.fdr_timing.argtypes = [vp, ctypes.c_int]
     L.fdr_timing_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(ctypes.c_float)]
@@ -265,6 +267,14 @@ class Context:
         counts = np.empty(n.value, dtype=np.uint64)
         self._check(self._L.fdr_kmer_count_fetch(self._h, codes.ctypes.data, counts.ctypes.data), "fdr_kmer_count_fetch")
         return codes, counts
+
+    def set_kmer_count_block(self, chars):
+        """Characters per block of kmer_count (0 = default 2^31); small blocks exercise the merge in tests."""
+        self._check(self._L.fdr_set_kmer_count_block(self._h, int(chars)), "fdr_set_kmer_count_block")
+
+    def last_kmer_count_blocks(self):
+        """Non-empty blocks the last kmer_count call counted."""
+        return int(self._L.fdr_last_kmer_count_blocks(self._h))
 
     def last_unique(self):
         """(unique target rows, unique query rows) searched by the last k-NN call."""

@@ -13,6 +13,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_merge.hpp>
+#include <rocprim/device/device_reduce_by_key.hpp>
 
 #include <algorithm>
 #include <cstdarg>
@@ -227,7 +229,10 @@ struct fdr_ctx {
     // k-mer search (kmer_search.inc)
     DevBuf ks_seq, ks_off, ks_codes, ks_keys, ks_vals, ks_bloom, ks_counter, ks_pairs, ks_pairs2, ks_flag, ks_pos,
         ks_idx, ks_rows, ks_indptr, ks_tmp, kc_counts;
+    DevBuf kc_a0, kc_a1, kc_c0, kc_c1, kc_mk, kc_mv, kc_rc;  // counting in blocks: accumulated table (ping / pong), merge buffers
     long long ks_nnz = 0, kc_n = 0;
+    int64_t kc_block_chars = 0;  // fdr_set_kmer_count_block
+    int kc_blocks = 0;           // blocks of the last fdr_kmer_count
     // timing: when enabled, every launch of kernel kind i gets its own hipEvent pair on the launch
     // stream; fdr_timing_read() sums the elapsed times of all launches since the last read
     int knn_mode = FDR_MODE_AUTO;
@@ -318,7 +323,8 @@ FDR_EXPORT int fdr_destroy(fdr_ctx *ctx) {
                       &ctx->Ehat, &ctx->zero, &ctx->idx, &ctx->dist, &ctx->ws,
                       &ctx->ks_seq, &ctx->ks_off, &ctx->ks_codes, &ctx->ks_keys, &ctx->ks_vals, &ctx->ks_bloom,
                       &ctx->ks_counter, &ctx->ks_pairs, &ctx->ks_pairs2, &ctx->ks_flag, &ctx->ks_pos,
-                      &ctx->ks_idx, &ctx->ks_rows, &ctx->ks_indptr, &ctx->ks_tmp, &ctx->kc_counts};
+                      &ctx->ks_idx, &ctx->ks_rows, &ctx->ks_indptr, &ctx->ks_tmp, &ctx->kc_counts,
+                      &ctx->kc_a0, &ctx->kc_a1, &ctx->kc_c0, &ctx->kc_c1, &ctx->kc_mk, &ctx->kc_mv, &ctx->kc_rc};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < FDR_NUM_KERNELS; ++i)
         for (hipEvent_t e : ctx->ev_pool[i]) (void)hipEventDestroy(e);

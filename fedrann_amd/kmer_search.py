@@ -130,10 +130,26 @@ def read_sequences(path, fastq_ids_as_fasta=False):
     return [x for x, ok in zip(ids, has_id) if ok], seqs, off
 
 
-def search(seqs, seq_off, lib_codes, k, context=None):
-    """(indptr int64 [R+1], indices int32) -- ascending unique library indices per read (GPU only)."""
+def search(seqs, seq_off, lib_codes, k, context=None, block_chars=1 << 31):
+    """(indptr int64 [R+1], indices int32) -- ascending unique library indices per read (GPU only).
+    Reads are independent, so read sets of more than block_chars characters go to the device in blocks of
+    whole reads (one call holds its reads, their hits and the sort buffers in HBM: about 28 B per base)."""
     ctx = context or _lib.default_context()
-    return ctx.kmer_search(seqs, seq_off, lib_codes, int(k))
+    seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+    R = seq_off.size - 1
+    if R <= 0 or int(seq_off[-1]) <= block_chars:
+        return ctx.kmer_search(seqs, seq_off, lib_codes, int(k))
+    ptr_parts, idx_parts, base, r0 = [np.zeros(1, dtype=np.int64)], [], 0, 0
+    while r0 < R:
+        # the reads r0 .. r1 - 1: at most block_chars characters, at least one read
+        r1 = int(np.searchsorted(seq_off, seq_off[r0] + block_chars, side="right")) - 1
+        r1 = min(max(r1, r0 + 1), R)
+        ip, ix = ctx.kmer_search(seqs[seq_off[r0]:seq_off[r1]], seq_off[r0:r1 + 1] - seq_off[r0], lib_codes, int(k))
+        ptr_parts.append(ip[1:] + base)
+        idx_parts.append(ix)
+        base += int(ip[-1])
+        r0 = r1
+    return np.concatenate(ptr_parts), np.concatenate(idx_parts) if idx_parts else np.empty(0, dtype=np.int32)
 
 
 def write_output_bin(path, ids, indptr, indices):

@@ -215,11 +215,17 @@ int fdr_kmer_search_indices(fdr_ctx *ctx, int32_t *indices_out);
  * the smaller of its 2-bit code and its reverse complement's.  fdr_kmer_count keeps the k-mers with at
  * least min_count occurrences on the device and returns their number; fdr_kmer_count_fetch copies
  * them out in ascending code order (jellyfish dumps in its hash order; the order only names the
- * features): codes_out, counts_out uint64 [n], and releases the device scratch.  Same size limits as
- * fdr_kmer_search. */
+ * features): codes_out, counts_out uint64 [n], and releases the device scratch.
+ * Any number of characters: read sets of 2^31 characters and more are counted in blocks of whole reads whose
+ * sorted (code, count) runs are merged into one table on the device; min_count applies to the totals.  Limits:
+ * n_reads < 2^31, one read < the block size, < 2^31 distinct k-mers.  fdr_set_kmer_count_block sets the block
+ * size in characters (0 = the default 2^31; for tests), fdr_last_kmer_count_blocks returns the number of
+ * non-empty blocks the last fdr_kmer_count call counted. */
 int fdr_kmer_count(fdr_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, int64_t n_reads, int32_t k,
                    int64_t min_count, int64_t *n_out);
 int fdr_kmer_count_fetch(fdr_ctx *ctx, uint64_t *codes_out, uint64_t *counts_out);
+int fdr_set_kmer_count_block(fdr_ctx *ctx, int64_t chars);
+int fdr_last_kmer_count_blocks(fdr_ctx *ctx);
 
 /* ---- kmer_searcher output.bin -> doubled binary CSR (host only: no context, no GPU) ---------------
  * Replaces fedrann/feature_extraction.py:108-140 (parse_kmer_searcher_output: header '<4sB3sQ' =

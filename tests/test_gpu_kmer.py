@@ -3,6 +3,7 @@ sets, incl. the reference's treatment of invalid characters, short and empty rea
 import numpy as np
 import pytest
 
+from fedrann_amd import _lib
 from fedrann_amd import feature_extraction as fx
 from fedrann_amd import kmer_search as ks
 from fedrann_amd.synth import synth_sequences
@@ -118,6 +119,44 @@ def test_kmer_count_matches_numpy_restatement(ctx, oracle, k, min_count):
     c2, n2 = ctx.kmer_count(np.frombuffer(b"".join(reads), dtype=np.uint8), o, k, 1)
     w2, m2 = oracle.kmer_count(reads, k, 1)
     assert np.array_equal(c2, w2) and np.array_equal(n2, m2)
+
+
+def test_kmer_search_in_blocks(ctx, oracle):
+    """kmer_search.search splits read sets beyond block_chars into blocks of whole reads: same CSR."""
+    s = synth_sequences(1200, genome_len=50_000, mean_len=1200, k=15, sample=0.02, n_rate=1e-3, seed=41)
+    codes = oracle.kmer_library(b"\n".join(s["fwd"] + s["rev"]), 15)
+    one = ks.search(s["seqs"], s["seq_off"], codes, 15, context=ctx)
+    many = ks.search(s["seqs"], s["seq_off"], codes, 15, context=ctx, block_chars=100_000)
+    tiny = ks.search(s["seqs"], s["seq_off"], codes, 15, context=ctx, block_chars=1)  # one read per call
+    for ip, ix in (many, tiny):
+        assert np.array_equal(ip, one[0]) and np.array_equal(ix, one[1])
+    wp, wx = oracle.kmer_search(_reads(s["seqs"], s["seq_off"]), codes, 15)
+    assert np.array_equal(one[0], wp) and np.array_equal(one[1], wx)
+
+
+@pytest.mark.parametrize("k,min_count,block", [(15, 2, 200_000), (9, 3, 50_000), (31, 1, 700_000)])
+def test_kmer_count_in_blocks(ctx, oracle, k, min_count, block):
+    """Read sets beyond one block's characters (2^31 by default; here a few hundred thousand) are counted block
+    by block and the runs merged on the device: the same table as in one piece and as the oracle's, thresholds
+    applied to the TOTALS (a k-mer seen once in each of two blocks passes min_count = 2)."""
+    s = synth_sequences(1500, genome_len=60_000, mean_len=1500, k=k, sample=0.01, n_rate=2e-3, seed=900 + k)
+    seqs, off = s["seqs"], s["seq_off"]
+    try:
+        ctx.set_kmer_count_block(0)
+        one = ctx.kmer_count(seqs, off, k, min_count)
+        assert ctx.last_kmer_count_blocks() == 1
+        ctx.set_kmer_count_block(block)
+        many = ctx.kmer_count(seqs, off, k, min_count)
+        assert ctx.last_kmer_count_blocks() >= 3
+        # a read longer than a block is refused, loudly
+        ctx.set_kmer_count_block(int(np.diff(off).max()))
+        with pytest.raises(_lib.FedrannHipError, match="characters"):
+            ctx.kmer_count(seqs, off, k, min_count)
+    finally:
+        ctx.set_kmer_count_block(0)
+    wc, wn = oracle.kmer_count(_reads(seqs, off), k, min_count)
+    assert np.array_equal(one[0], wc) and np.array_equal(one[1], wn)
+    assert np.array_equal(many[0], wc) and np.array_equal(many[1], wn)
 
 
 def test_run_kmer_searcher_from_reads_only(ctx, oracle, tmp_path):
