@@ -1040,6 +1040,9 @@ static DedupLayout dedup_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int 
     return L;
 }
 
+// queries (waves) per workgroup of expand_classes_kernel: four while their K * K keys stay within 32 KiB of LDS
+static int expand_waves_per_block(int k) { return (size_t)4 * k * k * 8 <= 32768 ? 4 : (size_t)2 * k * k * 8 <= 32768 ? 2 : 1; }
+
 static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
                       const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int d,
                       int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes, hipStream_t st) {
@@ -1151,7 +1154,8 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
                              L.inner_bytes, st);
     if (rc) return rc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_DEDUP, st))) return trc;
-    hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)nq), dim3(64), (size_t)k * k * 8, st, q0, (int)nq, k, (int)t_base,
+    const int xw = expand_waves_per_block(k);
+    hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)((nq + xw - 1) / xw)), dim3(64 * xw), (size_t)xw * k * k * 8, st, q0, (int)nq, k, (int)t_base,
                        (const int *)cls, (const int *)uofc, (const int *)uqpos, (const int *)idx_u,
                        (const float *)dist_u, (const int *)cofu, (const int *)cstart, (const int *)idx_s, d_idx,
                        d_dist);
@@ -1288,7 +1292,8 @@ FDR_EXPORT int fdr_knn_expand_dev(fdr_ctx *ctx, int64_t q0, int64_t nq, int64_t 
     char *ws = static_cast<char *>(ctx->cls.ws);
     int trc = timing_begin(ctx, FDR_KERNEL_KNN_DEDUP, st);
     if (trc) return trc;
-    hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)nq), dim3(64), (size_t)k * k * 8, st, (int)q0, (int)nq, k,
+    const int xw = expand_waves_per_block(k);
+    hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)((nq + xw - 1) / xw)), dim3(64 * xw), (size_t)xw * k * k * 8, st, (int)q0, (int)nq, k,
                        (int)t_base, (const int *)(ws + L.off_cls), (const int *)(ws + L.off_uofc), (const int *)nullptr,
                        (const int *)d_idx_u_all, d_dist_u_all, (const int *)(ws + L.off_cofu),
                        (const int *)(ws + L.off_cstart), (const int *)(ws + L.off_idx_s), d_idx, d_dist);
