@@ -178,6 +178,7 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restr
 #include "csr_compact.inc"        // dead-feature filter (plain C++)
 #include "knn_exact.inc"      // K3 / K4: fp32 MFMA tile kernel with LDS top-k lists, merge
 #include "knn_prefilter.inc"  // P1 / P2: fp16 MFMA candidate pass, merges, certificate + re-rank, range pass
+#include "knn_order.inc"      // P1: scan order by chunk mask (sort keys, ordered fp16 copy)
 #ifdef FDR_DEV
 #include "knn_prefilter2.inc" // P1, second shape (measured slower, development builds only): 256 queries / workgroup
 #else
@@ -525,6 +526,8 @@ struct PrefilterLayout {
     size_t off_ht, off_hq, off_cand, off_counter, off_flagged, off_qc, off_qzc, off_idxc, off_distc;
     size_t off_rlist, off_theta, off_hqc, off_thetac, off_cnt, off_rcand, total;  // range pass
     int rchunk;
+    int ordered;  // ordered scan possible: sort keys, order tables, ordered fp16 copies
+    size_t off_okeys, off_okeys_s, off_ovals, off_perm_t, off_perm_q, off_ho_t, off_ho_q, off_otmp, otmp_bytes;
     int sym;  // symmetric pass planned: threshold table, inbox counts, inboxes, the log and its chunk table
     size_t off_gthr, off_icnt, off_inbox, off_alloc, off_fill, off_erow, off_ekey;
     unsigned e_cap;
@@ -563,6 +566,23 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.off_thetac = o;   o += align256((size_t)L.rchunk * 4);
     L.off_cnt = o;      o += align256((size_t)L.rchunk * 4);
     L.off_rcand = o;    o += align256((size_t)L.rchunk * RANGE_CAP * 4);
+    L.ordered = pp.cohort > 0;  // (the sizes at which the pass runs in synchronised rounds)
+    L.off_okeys = L.off_okeys_s = L.off_ovals = L.off_perm_t = L.off_perm_q = L.off_ho_t = L.off_ho_q = 0;
+    L.off_otmp = L.otmp_bytes = 0;
+    if (L.ordered) {
+        L.off_okeys = o;    o += align256((size_t)nt * 8);
+        L.off_okeys_s = o;  o += align256((size_t)nt * 8);
+        L.off_ovals = o;    o += align256((size_t)nt * 4);
+        L.off_perm_t = o;   o += align256((size_t)nt * 4);
+        L.off_perm_q = o;   o += align256((size_t)nq * 4);
+        L.off_ho_t = o;     o += align256((size_t)nt * dp * 2);
+        L.off_ho_q = o;     o += align256((size_t)nq * dp * 2);
+        size_t t_sort = 0;
+        (void)rocprim::radix_sort_pairs(nullptr, t_sort, (u64 *)nullptr, (u64 *)nullptr, (int *)nullptr, (int *)nullptr,
+                                        (size_t)nt, 0, 40, (hipStream_t) nullptr);
+        L.otmp_bytes = align256(t_sort);
+        L.off_otmp = o;     o += L.otmp_bytes;
+    }
     L.sym = pp.sym;
     L.off_gthr = L.off_icnt = L.off_inbox = L.off_alloc = L.off_fill = L.off_erow = L.off_ekey = 0;
     L.e_cap = 0;
@@ -711,6 +731,34 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     hipLaunchKernelGGL(pack_zero_bits_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st,
                        d_tzero, (int)nt, d_bits, d_shared, p.nq_pad);
     HIP_TRY(hipGetLastError());
+    // Ordered scan (knn_order.inc): rows by chunk mask, fp16 copies in that order
+    OrderArgs ord = {nullptr, nullptr};
+    const _Float16 *p1_q = d_hq, *p1_t = d_ht;  // what the candidate pass streams
+    if (L.ordered && p.cohort > 0 && !p.sym && dev_env_int("FDR_KNN_ORDER", 1) != 0) {
+        u64 *okeys = reinterpret_cast<u64 *>(ws + L.off_okeys), *okeys_s = reinterpret_cast<u64 *>(ws + L.off_okeys_s);
+        int *ovals = reinterpret_cast<int *>(ws + L.off_ovals);
+        int *perm_t = reinterpret_cast<int *>(ws + L.off_perm_t), *perm_q = reinterpret_cast<int *>(ws + L.off_perm_q);
+        _Float16 *ho_t = reinterpret_cast<_Float16 *>(ws + L.off_ho_t);
+        _Float16 *ho_q = self ? ho_t : reinterpret_cast<_Float16 *>(ws + L.off_ho_q);
+        auto order = [&](const float *X, int64_t n, int *perm, _Float16 *out) -> int {
+            hipLaunchKernelGGL(row_chunk_keys_kernel, dim3((unsigned)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, st, X,
+                               (int)n, dp, okeys, ovals);
+            size_t tb = L.otmp_bytes;
+            HIP_TRY(rocprim::radix_sort_pairs(ws + L.off_otmp, tb, okeys, okeys_s, ovals, perm, (size_t)n, 0, 40, st));
+            const long long groups = (long long)n * (dp / 8);
+            hipLaunchKernelGGL(to_half_ordered_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, X,
+                               (const int *)perm, groups, dp / 8, out);
+            HIP_TRY(hipGetLastError());
+            return FDR_OK;
+        };
+        int orc;
+        if ((orc = order(d_That, nt, perm_t, ho_t))) return orc;
+        if (!self && (orc = order(d_Qhat, nq, perm_q, ho_q))) return orc;
+        ord.perm_t = perm_t;
+        ord.perm_q = self ? perm_t : perm_q;
+        p1_t = ho_t;
+        p1_q = ho_q;
+    }
     const size_t lds = knn_lds_bytes(sh, kp) + (size_t)dev_env_int("FDR_KNN_LDSPAD", 0);  // (development: fewer workgroups per CU)
     int max_seg = 1;
     for (int i = 0; i < p.nseg; ++i) max_seg = std::max(max_seg, p.segs.b[i + 1] - p.segs.b[i]);
@@ -723,7 +771,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
         // then starts warm -- what a perfect pre-pass could buy
         hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)(p.nqb * p.nseg)),
                            dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad,
-                           d_partial, d_shared, ib, 0, p.nqb, sym FDR_DBG_ARG(0));
+                           d_partial, d_shared, ib, 0, p.nqb, sym, ord FDR_DBG_ARG(0));
     }
 #endif
     const int pdbg = dev_env_int("FDR_KNN_DEBUG", 0);
@@ -767,8 +815,8 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             hipStream_t ls_ = qs[li % nqueues];                                                         \
             if (nqueues == 1 && (trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, ls_))) return trc;   \
             hipLaunchKernelGGL(KERNEL_, dim3((unsigned)std::min(per_launch, it_hi - base_)), dim3(THREADS_), lds, \
-                               ls_, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, \
-                               d_shared, ib, (int)base_, p.nqb, sym FDR_DBG_ARG(pdbg));                  \
+                               ls_, p1_q, (int)nq, p1_t, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, \
+                               d_shared, ib, (int)base_, p.nqb, sym, ord FDR_DBG_ARG(pdbg));             \
             if (nqueues == 1 && (trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, ls_))) return trc;     \
         }                                                                                               \
     } while (0)
