@@ -755,9 +755,11 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
         if ((orc = order(d_That, nt, perm_t, ho_t))) return orc;
         if (!self && (orc = order(d_Qhat, nq, perm_q, ho_q))) return orc;
         ord.perm_t = perm_t;
-        ord.perm_q = self ? perm_t : perm_q;
         p1_t = ho_t;
-        p1_q = ho_q;
+        if (dev_env_int("FDR_KNN_ORDER", 1) != 2) {  // (development, 2: the targets only)
+            ord.perm_q = self ? perm_t : perm_q;
+            p1_q = ho_q;
+        }
     }
     const size_t lds = knn_lds_bytes(sh, kp) + (size_t)dev_env_int("FDR_KNN_LDSPAD", 0);  // (development: fewer workgroups per CU)
     int max_seg = 1;
