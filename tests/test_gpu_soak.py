@@ -51,3 +51,29 @@ def test_random_cases_all_modes_agree(oracle, seed):
                 assert np.array_equal(xi, wi) and np.array_equal(xd.view(np.uint32), wd.view(np.uint32)), what
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("dedup", ["auto", "off"])
+def test_ordered_scan_with_exact_ties(dedup):
+    """The candidate pass scans > 131 k rows in chunk-mask order and keeps, among candidates at EQUAL approximate
+    distance, the ones it met first -- not the ones with the smallest row numbers.  Rows of a few distinct
+    magnitudes (plateaus of hundreds of exact ties around the k-th place) must still come out in (distance, row)
+    order: the certificate, the merge of the segment lists (whose bound once assumed row order inside a list) and
+    the range pass see to that."""
+    rng = np.random.default_rng(1234)
+    n, d, k = 300_000, 64, 20
+    E = rng.integers(-1, 2, size=(n, d)).astype(np.float32)
+    E[rng.random(E.shape) < 0.9] = 0
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_dedup_mode(dedup)
+        ctx.set_knn_mode("prefilter")
+        pi, pd = ctx.knn(E, k)
+        launches, queues = ctx.last_prefilter_launches()
+        assert launches > 1  # synchronised rounds: the sizes at which the scan is ordered
+        ctx.set_knn_mode("exact")
+        xi, xd = ctx.knn(E, k)
+    finally:
+        ctx.close()
+    assert np.array_equal(pi, xi)
+    assert np.array_equal(pd.view(np.uint32), xd.view(np.uint32))
