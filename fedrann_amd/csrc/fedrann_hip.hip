@@ -541,7 +541,7 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.chunk = (int)std::min<int64_t>(nq, 16384);
     const size_t exact_all = knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
     const int dp = fdr_padded_dim(d);
-    const KnnPlan pp = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp), sym && nq == nt);
+    const KnnPlan pp = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp, nq, ctx->num_cus), sym && nq == nt);
     // (a later call on fewer unique rows may plan more, shorter segments: room for the largest such plan)
     const size_t pre = std::max(pp.total_bytes, pp.bits_bytes + pp.shared_bytes +
                                                     prefilter_partial_bound(nq, nt, L.kp, pp.qw));
@@ -697,7 +697,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     const int kp = L.kp;
 
     const int dp = fdr_padded_dim(d);
-    const int pshape = prefilter_shape(dp, kp);
+    const int pshape = prefilter_shape(dp, kp, nq, ctx->num_cus);
     const KnnPlan p = knn_plan(ctx->num_cus, nq, nt, d, kp, pshape, L.sym != 0);
     const KnnShape &sh = kShapes[pshape];
     unsigned *d_bits = reinterpret_cast<unsigned *>(ws);
@@ -841,7 +841,12 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
             // <= 128 VGPRs.  FDR_KNN_PAIR=0: development knob, one chain)
             FDR_LAUNCH_SYM((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true, true>), 256)
-            FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
+#ifdef FDR_DEV
+            if (sh.nw == 16) FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 16, 4, 2, 16, true>), 1024);
+            else
+#endif
+            if (sh.nw == 8) FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512);
+            else FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
         } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
         else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
         else FDR_LAUNCH_PRE(512, 1, 4, 2, 2);

@@ -185,15 +185,15 @@ static int cmd_plan() {
                         ++n;
                         const int kp = (k + prefilter_extra() + 1) & ~1;
                         if (kp <= FDR_MAX_K && nt >= kp) {
-                            bad += check_plan(cus, nq, nt, d, kp, prefilter_shape(dp, kp));
+                            bad += check_plan(cus, nq, nt, d, kp, prefilter_shape(dp, kp, nq, cus));
                             bad += check_plan(cus, nq, nt, d, 1, range_shape(dp));
                             n += 2;
                         }
                     }
                 }
     // configs 4 / 5 of BASELINE.json: one rank's plan must fit FDR_MAX_SEG segments
-    const KnnPlan c4 = knn_plan(256, 1250000, 10000000, 128, 28, prefilter_shape(128, 28));
-    const KnnPlan c5 = knn_plan(256, 2500000, 20000000, 256, 58, prefilter_shape(256, 58));
+    const KnnPlan c4 = knn_plan(256, 1250000, 10000000, 128, 28, prefilter_shape(128, 28, 1250000, 256));
+    const KnnPlan c5 = knn_plan(256, 2500000, 20000000, 256, 58, prefilter_shape(256, 58, 2500000, 256));
     printf("rc=%d plans=%d config4_nseg=%d config5_nseg=%d\n", bad ? 1 : 0, n, c4.nseg, c5.nseg);
     return bad ? 1 : 0;
 }
