@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256, 4) void shape32_writes(const _Float16 *__restr
 // MODE 0: barrier only (no DMA), 1: DMA + barrier, 2: DMA + barrier, stages of four tiles (64 KiB ring, 2 WG/CU)
 template <int MODE, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 4) void shape32_staged(const _Float16 *__restrict__ q, const _Float16 *__restrict__ tg,
-                                                         int tiles, int *__restrict__ out) {
-    constexpr int TPS = MODE == 2 ? 4 : 2;  // tiles per stage
+                                                         int tiles, int *__restrict__ out, int twrap = 0x7fffffff) {
+    constexpr int TPS = MODE == 2 ? 4 : 2;  // (MODE 3: two tiles, staged through registers)  // tiles per stage
     extern __shared__ __attribute__((aligned(16))) f16x8 lds[];  // 2 stages x TPS tiles x 8 k-steps x 64 lanes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 2 * TPS * 512; i += 64 * NW) {
@@ -113,12 +113,19 @@ __global__ __launch_bounds__(64 * NW, 4) void shape32_staged(const _Float16 *__r
     int best = 0;
     const char *src = reinterpret_cast<const char *>(tg) + lane * 16;
     for (int t = 0, par = 0; t < tiles; t += TPS, par ^= 1) {
-        if (MODE >= 1) {
+        f16x8 stg[8 * TPS / NW];  // (MODE 3: the next stage's pieces travel through registers)
+        if (MODE == 3) {
+#pragma unroll
+            for (int u = 0; u < 8 * TPS / NW; ++u) {
+                const int piece = wave + NW * u;
+                stg[u] = *reinterpret_cast<const f16x8 *>(src + ((size_t)((t + TPS) & twrap) * 8 + piece) * 1024);
+            }
+        } else if (MODE >= 1) {
 #pragma unroll
             for (int u = 0; u < 8 * TPS / NW; ++u) {  // the next stage: TPS x 8 pieces, wave w takes pieces w, w + NW, ...
                 const int piece = wave + NW * u;
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + ((size_t)(t + TPS) * 8 + piece) * 1024),
+                    (const __attribute__((address_space(1))) void *)(src + ((size_t)((t + TPS) & twrap) * 8 + piece) * 1024),
                     (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(lds) + ((par ^ 1) * TPS * 8 + piece) * 1024),
                     16, 0, 0);
             }
@@ -141,6 +148,13 @@ __global__ __launch_bounds__(64 * NW, 4) void shape32_staged(const _Float16 *__r
             best = max(best, max(m0, m1));
         }
         if (__any(best == 0x7fffffff)) break;
+        if (MODE == 3) {
+#pragma unroll
+            for (int u = 0; u < 8 * TPS / NW; ++u) {
+                const int piece = wave + NW * u;
+                lds[((par ^ 1) * TPS * 8 + piece) * 64 + lane] = stg[u];
+            }
+        }
         __syncthreads();
     }
     if (best == 12345) out[0] = best;
@@ -214,7 +228,7 @@ int main() {
     CHECK(hipEventCreate(&e1));
     const double flops = (double)wgs * 4 * tiles * 32.0 * 32.0 * 128.0 * 2.0;
     for (int rep = 0; rep < 3; ++rep)
-        for (int which = 0; which < 10; ++which) {
+        for (int which = 0; which < 15; ++which) {
             CHECK(hipEventRecord(e0));
             if (which == 0) hipLaunchKernelGGL(shape32, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
             else if (which == 1) hipLaunchKernelGGL(shape16, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
@@ -223,6 +237,11 @@ int main() {
             else if (which == 4) hipLaunchKernelGGL(shape32_staged<2>, dim3(wgs), dim3(256), 65536, 0, q, tg, tiles, out);
             else if (which == 8) hipLaunchKernelGGL((shape32_staged<1, 8>), dim3(wgs / 2), dim3(512), 32768, 0, q, tg, tiles, out);
             else if (which == 9) hipLaunchKernelGGL((shape32_staged<1, 16>), dim3(wgs / 4), dim3(1024), 32768, 0, q, tg, tiles, out);
+            else if (which == 10) hipLaunchKernelGGL((shape32_staged<3, 4>), dim3(wgs), dim3(256), 32768, 0, q, tg, tiles, out);
+            else if (which == 11) hipLaunchKernelGGL((shape32_staged<3, 8>), dim3(wgs / 2), dim3(512), 32768, 0, q, tg, tiles, out);
+            else if (which == 12) hipLaunchKernelGGL((shape32_staged<1, 4>), dim3(wgs), dim3(256), 32768, 0, q, tg, tiles, out, 255);
+            else if (which == 13) hipLaunchKernelGGL((shape32_staged<1, 8>), dim3(wgs / 2), dim3(512), 32768, 0, q, tg, tiles, out, 255);
+            else if (which == 14) hipLaunchKernelGGL((shape32_staged<1, 4>), dim3(wgs), dim3(256), 32768, 0, q, tg, tiles, out, 4095);
             else if (which == 6) hipLaunchKernelGGL(shape32_writes<2>, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
             else if (which == 7) hipLaunchKernelGGL(shape32_writes<4>, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
             else {  // the shipped launch pattern: rounds of 512 workgroups dealt to two queues
@@ -252,7 +271,12 @@ int main() {
                                           "32x32x16 + LDS-DMA + barrier per four tiles (2 WG/CU)", "", "32x32x16 + 2 ds_write_b128 per wave and two tiles",
                                           "32x32x16 + 4 ds_write_b128 per wave and two tiles",
                                           "32x32x16 + LDS-DMA + barrier, 8 waves per workgroup (2 WG/CU)",
-                                          "32x32x16 + LDS-DMA + barrier, 16 waves per workgroup (1 WG/CU)"};
+                                          "32x32x16 + LDS-DMA + barrier, 16 waves per workgroup (1 WG/CU)",
+                                          "32x32x16 + global_load -> VGPR -> ds_write + barrier, 4 waves",
+                                          "32x32x16 + global_load -> VGPR -> ds_write + barrier, 8 waves",
+                                          "32x32x16 + LDS-DMA from a 2 MB window (L2-resident), 4 waves",
+                                          "32x32x16 + LDS-DMA from a 2 MB window (L2-resident), 8 waves",
+                                          "32x32x16 + LDS-DMA from a 32 MB window, 4 waves"};
             printf("%-56s %.1f ms  %.3f PFLOP/s  (%.3f of 2.5)\n", names[which], ms, flops / ms / 1e12, flops / ms / 1e12 / 2.5);
         }
     return 0;
