@@ -160,6 +160,52 @@ __global__ __launch_bounds__(64 * NW, 4) void shape32_staged(const _Float16 *__r
     if (best == 12345) out[0] = best;
 }
 
+// 32x32x16 with a DEEPER ring in the same 32 KiB: RING stages of TPS tiles each (RING * TPS = 4 tiles), the stage that is
+// fetched is RING - 1 stages ahead of the one that is multiplied; one barrier per stage
+template <int RING, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void shape32_ring(const _Float16 *__restrict__ q, const _Float16 *__restrict__ tg,
+                                                       int tiles, int *__restrict__ out) {
+    constexpr int TPS = 4 / RING;
+    extern __shared__ __attribute__((aligned(16))) f16x8 lds[];  // 4 tiles x 8 k-steps x 64 lanes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f16x8 b[8];
+    for (int s = 0; s < 8; ++s) b[s] = reinterpret_cast<const f16x8 *>(q)[((blockIdx.x * NW + wave) & 32767) * 512 + s * 64 + lane];
+    const char *src = reinterpret_cast<const char *>(tg) + lane * 16;
+    auto issue = [&](int stage) {  // stage number -> ring slot stage % RING
+#pragma unroll
+        for (int u = 0; u < 8 * TPS / NW; ++u) {
+            const int piece = wave + NW * u;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + ((size_t)stage * TPS * 8 + piece) * 1024),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<char *>(lds) + ((stage % RING) * TPS * 8 + piece) * 1024),
+                16, 0, 0);
+        }
+    };
+    for (int st = 0; st < RING - 1; ++st) issue(st);
+    int best = 0;
+    const int nstages = tiles / TPS;
+    for (int st = 0; st < nstages; ++st) {
+        // the stage multiplied now was issued RING - 1 stages ago: wait for all but the RING - 2 younger ones
+        if (RING == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (8 / 4 / NW > 0 ? 8 / 4 / NW : 1)) : "memory");
+        else if (RING == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue(st + RING - 1);  // (its slot was read RING stages... one stage ago at the latest: safe after the barrier)
+        const f16x8 *base = lds + (st % RING) * TPS * 512;
+#pragma unroll
+        for (int tl = 0; tl < TPS; ++tl) {
+            f32x16 a0 = {};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(base[tl * 512 + s * 64 + lane], b[s], a0, 0, 0, 0);
+            int m0 = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) m0 = max(max(m0, __float_as_int(a0[r])), __float_as_int(a0[r + 1]));
+            best = max(best, m0);
+        }
+        if (__any(best == 0x7fffffff)) break;
+    }
+    if (best == 12345) out[0] = best;
+}
+
 // 16x16x32: the same 32 x 32 x 128 block as 2 row blocks x 2 column blocks x 4 k-steps = 16 MFMAs on 4 accumulators of
 // 4 registers; 8 A fragments from LDS, each used for both column blocks
 __global__ __launch_bounds__(256, 4) void shape16(const _Float16 *__restrict__ q, int tiles, int *__restrict__ out) {
@@ -228,7 +274,7 @@ int main() {
     CHECK(hipEventCreate(&e1));
     const double flops = (double)wgs * 4 * tiles * 32.0 * 32.0 * 128.0 * 2.0;
     for (int rep = 0; rep < 3; ++rep)
-        for (int which = 0; which < 15; ++which) {
+        for (int which = 0; which < 18; ++which) {
             CHECK(hipEventRecord(e0));
             if (which == 0) hipLaunchKernelGGL(shape32, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
             else if (which == 1) hipLaunchKernelGGL(shape16, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
@@ -242,6 +288,9 @@ int main() {
             else if (which == 12) hipLaunchKernelGGL((shape32_staged<1, 4>), dim3(wgs), dim3(256), 32768, 0, q, tg, tiles, out, 255);
             else if (which == 13) hipLaunchKernelGGL((shape32_staged<1, 8>), dim3(wgs / 2), dim3(512), 32768, 0, q, tg, tiles, out, 255);
             else if (which == 14) hipLaunchKernelGGL((shape32_staged<1, 4>), dim3(wgs), dim3(256), 32768, 0, q, tg, tiles, out, 4095);
+            else if (which == 15) hipLaunchKernelGGL((shape32_ring<2, 4>), dim3(wgs), dim3(256), 32768, 0, q, tg, tiles, out);
+            else if (which == 16) hipLaunchKernelGGL((shape32_ring<4, 4>), dim3(wgs), dim3(256), 32768, 0, q, tg, tiles, out);
+            else if (which == 17) hipLaunchKernelGGL((shape32_ring<4, 8>), dim3(wgs / 2), dim3(512), 32768, 0, q, tg, tiles, out);
             else if (which == 6) hipLaunchKernelGGL(shape32_writes<2>, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
             else if (which == 7) hipLaunchKernelGGL(shape32_writes<4>, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
             else {  // the shipped launch pattern: rounds of 512 workgroups dealt to two queues
@@ -276,7 +325,10 @@ int main() {
                                           "32x32x16 + global_load -> VGPR -> ds_write + barrier, 8 waves",
                                           "32x32x16 + LDS-DMA from a 2 MB window (L2-resident), 4 waves",
                                           "32x32x16 + LDS-DMA from a 2 MB window (L2-resident), 8 waves",
-                                          "32x32x16 + LDS-DMA from a 32 MB window, 4 waves"};
+                                          "32x32x16 + LDS-DMA from a 32 MB window, 4 waves",
+                                          "ring of 2 two-tile stages, barrier first (reference for the next two), 4 waves",
+                                          "ring of 4 one-tile stages, fetched 3 stages ahead, 4 waves",
+                                          "ring of 4 one-tile stages, fetched 3 stages ahead, 8 waves"};
             printf("%-56s %.1f ms  %.3f PFLOP/s  (%.3f of 2.5)\n", names[which], ms, flops / ms / 1e12, flops / ms / 1e12 / 2.5);
         }
     return 0;
