@@ -6,6 +6,7 @@
 //   hipcc --offload-arch=gfx950 -O3 devtools/mfma_shape_bench.hip -o gpurun_out/mfma_shape_bench && ./gpurun_out/mfma_shape_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -91,6 +92,51 @@ __global__ __launch_bounds__(256, 4) void shape32_writes(const _Float16 *__restr
         if (__any(best == 0x7fffffff)) break;
     }
     if (best == 12345) out[0] = best + (int)scratch[lane][0];
+}
+
+// 32x32x16 + NV extra vector instructions and NS extra scalar instructions per tile (the shipped kernel issues ~44
+// vector and ~12 scalar instructions per wave and tile beside its 8 MFMAs)
+template <int NV, int NS>
+__global__ __launch_bounds__(256, 4) void shape32_valu(const _Float16 *__restrict__ q, int tiles, int *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) f16x8 lds[2 * 8 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * 8 * 64; i += 256) {
+        f16x8 v;
+        for (int c = 0; c < 8; ++c) v[c] = (_Float16)(sparse_value((unsigned)(i * 8 + c) * 2654435761u + blockIdx.x));
+        lds[i] = v;
+    }
+    f16x8 b[8];
+    for (int s = 0; s < 8; ++s) b[s] = reinterpret_cast<const f16x8 *>(q)[(blockIdx.x * 4 + wave) * 512 + s * 64 + lane];
+    __syncthreads();
+    int best = 0;
+    unsigned x0 = lane, x1 = lane * 3u, x2 = lane * 5u, x3 = lane * 7u;  // four independent chains
+    unsigned s0 = blockIdx.x;
+    for (int t = 0; t < tiles; t += 2) {
+        f32x16 a0 = {}, a1 = {};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds[s * 64 + lane], b[s], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds[512 + s * 64 + lane], b[s], a1, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < NV / 4; ++e) {  // 2 tiles x NV / 8 steps / 4 chains... = NV per tile in total
+                asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x0) : "v"(x1));
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(x1) : "v"(x2));
+                asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x2) : "v"(x3));
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(x3) : "v"(x0));
+            }
+#pragma unroll
+            for (int e = 0; e < NS / 4; ++e) asm volatile("s_add_u32 %0, %0, 1\n s_xor_b32 %0, %0, 5\n s_add_u32 %0, %0, 3\n s_xor_b32 %0, %0, 9" : "+s"(s0) : : "scc");
+        }
+        int m0 = 0, m1 = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            m0 = max(max(m0, __float_as_int(a0[r])), __float_as_int(a0[r + 1]));
+            m1 = max(max(m1, __float_as_int(a1[r])), __float_as_int(a1[r + 1]));
+        }
+        best = max(best, max(m0, m1));
+        if (__any(best == 0x7fffffff)) break;
+    }
+    if (best == 12345) out[0] = best + (int)(x0 + x1 + x2 + x3 + s0);
 }
 
 // 32x32x16 with the shipped kernel's staging: a ring of two stages of two tiles (32 KiB), every wave fetches four
@@ -248,7 +294,8 @@ __global__ __launch_bounds__(256, 4) void shape16(const _Float16 *__restrict__ q
     if (best == 12345) out[0] = best;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const int first = argc > 1 ? atoi(argv[1]) : 0, reps = argc > 2 ? atoi(argv[2]) : 3;
     const int wgs = 1024 * 8;  // 8 rounds of 4 workgroups per CU
     const int tiles = 26000;   // one scan of 831 k rows
     _Float16 *q;
@@ -273,8 +320,8 @@ int main() {
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     const double flops = (double)wgs * 4 * tiles * 32.0 * 32.0 * 128.0 * 2.0;
-    for (int rep = 0; rep < 3; ++rep)
-        for (int which = 0; which < 18; ++which) {
+    for (int rep = 0; rep < reps; ++rep)
+        for (int which = first; which < 22; ++which) {
             CHECK(hipEventRecord(e0));
             if (which == 0) hipLaunchKernelGGL(shape32, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
             else if (which == 1) hipLaunchKernelGGL(shape16, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
@@ -291,6 +338,10 @@ int main() {
             else if (which == 15) hipLaunchKernelGGL((shape32_ring<2, 4>), dim3(wgs), dim3(256), 32768, 0, q, tg, tiles, out);
             else if (which == 16) hipLaunchKernelGGL((shape32_ring<4, 4>), dim3(wgs), dim3(256), 32768, 0, q, tg, tiles, out);
             else if (which == 17) hipLaunchKernelGGL((shape32_ring<4, 8>), dim3(wgs / 2), dim3(512), 32768, 0, q, tg, tiles, out);
+            else if (which == 18) hipLaunchKernelGGL((shape32_valu<16, 0>), dim3(wgs), dim3(256), 0, 0, q, tiles, out);
+            else if (which == 19) hipLaunchKernelGGL((shape32_valu<32, 0>), dim3(wgs), dim3(256), 0, 0, q, tiles, out);
+            else if (which == 20) hipLaunchKernelGGL((shape32_valu<64, 0>), dim3(wgs), dim3(256), 0, 0, q, tiles, out);
+            else if (which == 21) hipLaunchKernelGGL((shape32_valu<32, 32>), dim3(wgs), dim3(256), 0, 0, q, tiles, out);
             else if (which == 6) hipLaunchKernelGGL(shape32_writes<2>, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
             else if (which == 7) hipLaunchKernelGGL(shape32_writes<4>, dim3(wgs), dim3(256), 0, 0, q, tiles, out);
             else {  // the shipped launch pattern: rounds of 512 workgroups dealt to two queues
@@ -328,8 +379,12 @@ int main() {
                                           "32x32x16 + LDS-DMA from a 32 MB window, 4 waves",
                                           "ring of 2 two-tile stages, barrier first (reference for the next two), 4 waves",
                                           "ring of 4 one-tile stages, fetched 3 stages ahead, 4 waves",
-                                          "ring of 4 one-tile stages, fetched 3 stages ahead, 8 waves"};
+                                          "ring of 4 one-tile stages, fetched 3 stages ahead, 8 waves",
+                                          "32x32x16 + 16 extra vector instructions per tile", "32x32x16 + 32 extra vector instructions per tile",
+                                          "32x32x16 + 64 extra vector instructions per tile",
+                                          "32x32x16 + 32 extra vector + 32 extra scalar instructions per tile"};
             printf("%-56s %.1f ms  %.3f PFLOP/s  (%.3f of 2.5)\n", names[which], ms, flops / ms / 1e12, flops / ms / 1e12 / 2.5);
+            fflush(stdout);
         }
     return 0;
 }
