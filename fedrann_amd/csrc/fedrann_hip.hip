@@ -179,11 +179,6 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restr
 #include "knn_exact.inc"      // K3 / K4: fp32 MFMA tile kernel with LDS top-k lists, merge
 #include "knn_prefilter.inc"  // P1 / P2: fp16 MFMA candidate pass, merges, certificate + re-rank, range pass
 #include "knn_order.inc"      // P1: scan order by chunk mask (sort keys, ordered fp16 copy)
-#ifdef FDR_DEV
-#include "knn_prefilter2.inc" // P1, second shape (measured slower, development builds only): 256 queries / workgroup
-#else
-#define PF2_PAD_ROWS 0
-#endif
 #include "dedup_classes.inc"  // duplicate-row classes: hash, tables, gathers, expansion
 
 // ------------------------------------------------------------------------------------------
@@ -528,20 +523,17 @@ struct PrefilterLayout {
     int rchunk;
     int ordered;  // ordered scan possible: sort keys, order tables, ordered fp16 copies
     size_t off_okeys, off_okeys_s, off_ovals, off_perm_t, off_perm_q, off_ho_t, off_ho_q, off_otmp, otmp_bytes;
-    int sym;  // symmetric pass planned: threshold table, inbox counts, inboxes, the log and its chunk table
-    size_t off_gthr, off_icnt, off_inbox, off_alloc, off_fill, off_erow, off_ekey;
-    unsigned e_cap;
 };
 
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k, bool sym = false) {
+static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
     PrefilterLayout L;
     L.kp = (k + prefilter_extra() + 1) & ~1;
     L.chunk = (int)std::min<int64_t>(nq, 16384);
     const size_t exact_all = knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
     const int dp = fdr_padded_dim(d);
-    const KnnPlan pp = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp, nq, ctx->num_cus), sym && nq == nt);
+    const KnnPlan pp = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp, nq, ctx->num_cus));
     // (a later call on fewer unique rows may plan more, shorter segments: room for the largest such plan)
     const size_t pre = std::max(pp.total_bytes, pp.bits_bytes + pp.shared_bytes +
                                                     prefilter_partial_bound(nq, nt, L.kp, pp.qw));
@@ -550,7 +542,7 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
                                (size_t)FDR_MAX_SEG * (L.chunk + 128) * (size_t)k * 8;
     L.knn_bytes = align256(std::max(exact_all, std::max(pre, chunk_bound)));
     size_t o = L.knn_bytes;
-    L.off_ht = o;       o += align256((size_t)(nt + PF2_PAD_ROWS) * dp * 2);  // (+ readable rows behind the copy)
+    L.off_ht = o;       o += align256((size_t)nt * dp * 2);
     L.off_hq = o;       o += align256((size_t)nq * dp * 2);
     L.off_cand = o;     o += align256((size_t)nq * L.kp * 8);
     L.off_counter = o;  o += 1024;  // [0] exact list, [1] all-zero queries, [2] range list; zero answer at +256 / +512
@@ -582,20 +574,6 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
                                         (size_t)nt, 0, 40, (hipStream_t) nullptr);
         L.otmp_bytes = align256(t_sort);
         L.off_otmp = o;     o += L.otmp_bytes;
-    }
-    L.sym = pp.sym;
-    L.off_gthr = L.off_icnt = L.off_inbox = L.off_alloc = L.off_fill = L.off_erow = L.off_ekey = 0;
-    L.e_cap = 0;
-    if (L.sym) {
-        L.off_gthr = o;   o += align256((size_t)((nt + 31) / 32) * 16);
-        L.off_icnt = o;   o += align256((size_t)nt * 4);
-        L.off_inbox = o;  o += align256((size_t)nt * SYM_INBOX_CAP * 8);
-        const size_t per_row = (size_t)std::max(64, dev_env_int("FDR_KNN_SYM_LOG", 512));  // log entries per row
-        L.e_cap = (unsigned)std::min<size_t>((size_t)0xffff0000u, ((size_t)nt * per_row + SYM_CHUNK - 1) / SYM_CHUNK * SYM_CHUNK);
-        L.off_alloc = o;  o += 256;
-        L.off_fill = o;   o += align256((size_t)(L.e_cap / SYM_CHUNK) * 4);
-        L.off_erow = o;   o += align256((size_t)L.e_cap * 4);
-        L.off_ekey = o;   o += align256((size_t)L.e_cap * 8);
     }
     L.total = o;
     return L;
@@ -677,11 +655,10 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
 static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
                                 const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base,
                                 int d, int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes,
-                                hipStream_t st, bool allow_sym = true) {
-    // the queries ARE the targets (row i of one is row i of the other): the symmetric pass applies
+                                hipStream_t st) {
+    // the queries ARE the targets (row i of one is row i of the other): one fp16 copy serves both sides
     const bool self = d_Qhat == d_That && d_qzero == d_tzero && nq == nt;
-    PrefilterLayout L = prefilter_layout(ctx, nq, nt, d, k, self && allow_sym);
-    if (L.sym && ws_bytes < L.total) L = prefilter_layout(ctx, nq, nt, d, k, false);  // (a workspace sized for more queries than targets)
+    const PrefilterLayout L = prefilter_layout(ctx, nq, nt, d, k);
     if (ws_bytes < L.total)
         return fail(FDR_E_ARG, "knn: workspace %zu < required %zu bytes", ws_bytes, L.total);
     char *ws = static_cast<char *>(d_ws);
@@ -698,7 +675,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
 
     const int dp = fdr_padded_dim(d);
     const int pshape = prefilter_shape(dp, kp, nq, ctx->num_cus);
-    const KnnPlan p = knn_plan(ctx->num_cus, nq, nt, d, kp, pshape, L.sym != 0);
+    const KnnPlan p = knn_plan(ctx->num_cus, nq, nt, d, kp, pshape);
     const KnnShape &sh = kShapes[pshape];
     unsigned *d_bits = reinterpret_cast<unsigned *>(ws);
     unsigned *d_shared = reinterpret_cast<unsigned *>(ws + p.bits_bytes);
@@ -711,30 +688,13 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     if (!self)
         hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((nq * (dp / 8) + 255) / 256)), dim3(256), 0, st, d_Qhat,
                            (long long)nq * (dp / 8), d_hq);
-    SymArgs sym = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 1, 1};
-    int *d_icnt = nullptr;
-    u64 *d_inbox = nullptr;
-    if (p.sym) {
-        sym.gthr = reinterpret_cast<const int *>(ws + L.off_gthr);
-        sym.alloc = reinterpret_cast<unsigned *>(ws + L.off_alloc);
-        sym.fill = reinterpret_cast<int *>(ws + L.off_fill);
-        sym.e_row = reinterpret_cast<unsigned *>(ws + L.off_erow);
-        sym.e_key = reinterpret_cast<u64 *>(ws + L.off_ekey);
-        sym.e_cap = L.e_cap;
-        sym.seg_rows = p.segs.b[1] - p.segs.b[0];
-        sym.nseg = p.nseg;
-        d_icnt = reinterpret_cast<int *>(ws + L.off_icnt);
-        d_inbox = reinterpret_cast<u64 *>(ws + L.off_inbox);
-        HIP_TRY(hipMemsetAsync(d_icnt, 0, (size_t)nt * 4, st));
-        HIP_TRY(hipMemsetAsync(sym.alloc, 0, 256, st));
-    }
     hipLaunchKernelGGL(pack_zero_bits_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st,
                        d_tzero, (int)nt, d_bits, d_shared, p.nq_pad);
     HIP_TRY(hipGetLastError());
     // Ordered scan (knn_order.inc): rows by chunk mask, fp16 copies in that order
     OrderArgs ord = {nullptr, nullptr};
     const _Float16 *p1_q = d_hq, *p1_t = d_ht;  // what the candidate pass streams
-    if (L.ordered && p.cohort > 0 && !p.sym && dev_env_int("FDR_KNN_ORDER", 1) != 0) {
+    if (L.ordered && p.cohort > 0) {
         u64 *okeys = reinterpret_cast<u64 *>(ws + L.off_okeys), *okeys_s = reinterpret_cast<u64 *>(ws + L.off_okeys_s);
         int *ovals = reinterpret_cast<int *>(ws + L.off_ovals);
         int *perm_t = reinterpret_cast<int *>(ws + L.off_perm_t), *perm_q = reinterpret_cast<int *>(ws + L.off_perm_q);
@@ -756,30 +716,19 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
         if (!self && (orc = order(d_Qhat, nq, perm_q, ho_q))) return orc;
         ord.perm_t = perm_t;
         p1_t = ho_t;
-        if (dev_env_int("FDR_KNN_ORDER", 1) != 2) {  // (development, 2: the targets only)
-            ord.perm_q = self ? perm_t : perm_q;
-            p1_q = ho_q;
-        }
+        ord.perm_q = self ? perm_t : perm_q;
+        p1_q = ho_q;
     }
-    const size_t lds = knn_lds_bytes(sh, kp) + (size_t)dev_env_int("FDR_KNN_LDSPAD", 0);  // (development: fewer workgroups per CU)
+    const size_t lds = knn_lds_bytes(sh, kp);
     int max_seg = 1;
     for (int i = 0; i < p.nseg; ++i) max_seg = std::max(max_seg, p.segs.b[i + 1] - p.segs.b[i]);
     const int ib = prefilter_index_bits(max_seg);
     if (ib > FDR_PREFILTER_MAX_IB) return fail(FDR_E_ARG, "knn prefilter: segment of %d rows", max_seg);
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
-#ifdef FDR_DEV
-    if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_WARM", 0) != 0) {
-        // experiment: an untimed first pass leaves every query's FINAL bound in d_shared; the timed pass below
-        // then starts warm -- what a perfect pre-pass could buy
-        hipLaunchKernelGGL((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), dim3((unsigned)(p.nqb * p.nseg)),
-                           dim3(256), lds, st, d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad,
-                           d_partial, d_shared, ib, 0, p.nqb, sym, ord FDR_DBG_ARG(0));
-    }
-#endif
     const int pdbg = dev_env_int("FDR_KNN_DEBUG", 0);
     (void)pdbg;
-    // the nqb * nslot work items in launches of p.cohort workgroups (0: one launch): see knn_plan_compute
-    const long long n_items = (long long)p.nqb * p.nslot;
+    // the nqb * nseg work items in launches of p.cohort workgroups (0: one launch): see knn_plan_compute
+    const long long n_items = (long long)p.nqb * p.nseg;
     const long long per_launch = p.cohort > 0 ? p.cohort : n_items;
     // Several queues: with the launches of the synchronised rounds dealt round-robin to the caller's stream and
     // further ones, the workgroups of a later launch take the slots the stragglers of an earlier one have
@@ -818,33 +767,20 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             if (nqueues == 1 && (trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, ls_))) return trc;   \
             hipLaunchKernelGGL(KERNEL_, dim3((unsigned)std::min(per_launch, it_hi - base_)), dim3(THREADS_), lds, \
                                ls_, p1_q, (int)nq, p1_t, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, \
-                               d_shared, ib, (int)base_, p.nqb, sym, ord FDR_DBG_ARG(pdbg));             \
+                               d_shared, ib, (int)base_, p.nqb, ord FDR_DBG_ARG(pdbg));             \
             if (nqueues == 1 && (trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, ls_))) return trc;     \
         }                                                                                               \
     } while (0)
-#ifdef FDR_DEV  /* (the symmetric pass exists in development builds only: measured slower) */
-#define FDR_LAUNCH_SYM(KERNEL_, THREADS_) if (p.sym) FDR_LAUNCH_PRE3(KERNEL_, THREADS_); else
-#else
-#define FDR_LAUNCH_SYM(KERNEL_, THREADS_)
-#endif
 #define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_) /* (the ring is at most 32 KB: no dynamic-LDS attribute) */ \
-    do {                                                                                                \
-        FDR_LAUNCH_SYM((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_, false, true>), 64 * NW_)     \
-        FDR_LAUNCH_PRE3((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>), 64 * NW_);                \
-    } while (0)
+    FDR_LAUNCH_PRE3((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>), 64 * NW_)
 #define FDR_LAUNCH_PRE(DP_, NQ_, NW_, WPS_, U_)                                                         \
     do {                                                                                                \
         if (kp <= 32) FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 16);                                     \
         else FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 32);                                              \
     } while (0)
-        if (dp == 128 && kp <= 32 && dev_env_int("FDR_KNN_PAIR", 1) != 0) {
+        if (dp == 128 && kp <= 32) {
             // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
-            // <= 128 VGPRs.  FDR_KNN_PAIR=0: development knob, one chain)
-            FDR_LAUNCH_SYM((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true, true>), 256)
-#ifdef FDR_DEV
-            if (sh.nw == 16) FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 16, 4, 2, 16, true>), 1024);
-            else
-#endif
+            // <= 128 VGPRs)
             if (sh.nw == 8) FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512);
             else FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
         } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
@@ -853,48 +789,12 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
 #undef FDR_LAUNCH_PRE3
 #undef FDR_LAUNCH_PRE2
 #undef FDR_LAUNCH_PRE
-#undef FDR_LAUNCH_SYM
         HIP_TRY(hipGetLastError());
         return FDR_OK;
     };
     int lrc;
     if ((lrc = fork())) return lrc;
-#ifdef FDR_DEV
-    if (pshape == FDR_SHAPE_PREFILTER2) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_prefilter2_kernel<16>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
-        hipLaunchKernelGGL((knn_prefilter2_kernel<16>), dim3((unsigned)p.nqb, (unsigned)p.nseg), dim3(256), lds, st,
-                           d_hq, (int)nq, d_ht, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, d_shared,
-                           ib FDR_DBG_ARG(pdbg));
-        if ((trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
-        li = 1;
-    } else
-#endif
-    if (!p.sym) {
-        if ((lrc = launch_items(0, n_items))) return lrc;
-    } else {
-        // symmetric pass, slot-major: slot 0 (every query block against its own segment) gives every row a bound;
-        // then the table of group thresholds the other side's test reads is made from the bounds (complete for
-        // slot 0: both queues are joined once) and refreshed after every further slot's launches WITHOUT
-        // waiting for the other queue -- an older table is only looser (see sym_group_thresholds_kernel)
-        const int ngroups = (int)((nt + 31) / 32) * 4;
-        const int refresh = dev_env_int("FDR_KNN_SYM_REFRESH", 1);  // development knob: 0 = only after slot 0, 2 = joined
-        for (int slot = 0; slot < p.nslot; ++slot) {
-            if ((lrc = launch_items((long long)slot * p.nqb, (long long)(slot + 1) * p.nqb))) return lrc;
-            if (slot + 1 == p.nslot || (slot > 0 && refresh == 0)) continue;
-            if (slot == 0 || refresh == 2) {
-                if ((lrc = join())) return lrc;
-            }
-            hipLaunchKernelGGL(sym_group_thresholds_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st,
-                               (const unsigned *)d_shared, (int)nt, ib, const_cast<int *>(sym.gthr), ngroups,
-                               refresh == 3 ? 1 : 0);
-            HIP_TRY(hipGetLastError());
-            if (slot == 0 || refresh == 2) {
-                if ((lrc = fork())) return lrc;
-            }
-        }
-    }
+    if ((lrc = launch_items(0, n_items))) return lrc;
     ctx->last_pass_launches = li;
     ctx->last_pass_queues = nqueues;
     if ((lrc = join())) return lrc;  // the merge below (on `st`) needs the other queues' launches too
@@ -912,37 +812,16 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
 #endif
 
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
-    if (p.sym) {
-        hipLaunchKernelGGL(sym_scatter_kernel, dim3(L.e_cap / SYM_CHUNK), dim3(SYM_CHUNK), 0, st,
-                           (const unsigned *)sym.alloc, (const int *)sym.fill, (const unsigned *)sym.e_row,
-                           (const u64 *)sym.e_key, (const unsigned *)d_shared, ib, (int)t_base, d_icnt, d_inbox,
-                           SYM_INBOX_CAP);
-        HIP_TRY(hipGetLastError());
-        if (dev_env_int("FDR_KNN_DEBUG", 0) & 32) {  // (development: log and inbox volumes)
-            unsigned al[2];
-            HIP_TRY(hipMemcpyAsync(al, sym.alloc, 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            std::vector<int> hc((size_t)nt);
-            HIP_TRY(hipMemcpy(hc.data(), d_icnt, (size_t)nt * 4, hipMemcpyDeviceToHost));
-            long long tot = 0, over = 0;
-            int mx = 0;
-            for (int v : hc) { tot += v; over += v > SYM_INBOX_CAP; mx = std::max(mx, v); }
-            fprintf(stderr, "[fdr sym] log entries handed out %u of %u (overflow %u), inbox entries %lld (%.1f per row, max %d, rows over %d: %lld)\n",
-                    al[0], L.e_cap, al[1], tot, (double)tot / (double)nt, mx, SYM_INBOX_CAP, over);
-        }
-    }
     hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
-                       (const u64 *)d_partial, p.nslot, (int)nq, p.nq_pad, kp, d_cand, (const int *)d_icnt,
-                       (const u64 *)d_inbox, SYM_INBOX_CAP);
+                       (const u64 *)d_partial, p.nseg, (int)nq, p.nq_pad, kp, d_cand);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(d_counter, 0, 16, st));
     int *d_rlist = reinterpret_cast<int *>(ws + L.off_rlist);
     float *d_theta = reinterpret_cast<float *>(ws + L.off_theta);
-    const bool use_range = dev_env_int("FDR_KNN_RANGE", 1) != 0;  // dev knob
     const float margin = 2.0f * prefilter_eps(ib) + 4.0e-7f;
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
                        (const u64 *)d_cand, kp, k, d_Qhat, d_qzero, d_That, (int)nq, dp, (int)t_base, margin,
-                       d_idx, d_dist, d_counter, d_flagged, use_range ? d_rlist : (int *)nullptr, d_theta);
+                       d_idx, d_dist, d_counter, d_flagged, d_rlist, d_theta);
     {   // all-zero queries share one closed-form answer (their number is only known on the device yet)
         int *d_zidx = d_counter + 64;
         float *d_zdist = reinterpret_cast<float *>(d_counter + 128);
@@ -958,13 +837,8 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     // how many queries could not be certified / are all-zero / need a range pass?  (one 12-byte
     // read-back; the passes below are sized from it)
     int counts[3] = {0, 0, 0};
-    unsigned log_state[2] = {0u, 0u};
     HIP_TRY(hipMemcpyAsync(counts, d_counter, 12, hipMemcpyDeviceToHost, st));
-    if (p.sym) HIP_TRY(hipMemcpyAsync(log_state, sym.alloc, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (log_state[1] != 0u)  // the symmetric pass's log overflowed (never seen): the plain pass instead
-        return launch_knn_prefilter(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist, d_ws,
-                                    ws_bytes, st, false);
     int count = counts[0];
     const int zcount = counts[1], rcount = counts[2];
     ctx->last_flagged = count + rcount;
@@ -1023,11 +897,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
 }
 
 static size_t knn_mode_workspace_bytes(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
-    if (knn_prefilter_wanted(ctx, fdr_padded_dim(d), nt, k)) {
-        const size_t plain = prefilter_layout(ctx, nq, nt, d, k).total;
-        // (as many queries as targets: they may BE the targets -- room for the symmetric pass's inboxes)
-        return nq == nt ? std::max(plain, prefilter_layout(ctx, nq, nt, d, k, true).total) : plain;
-    }
+    if (knn_prefilter_wanted(ctx, fdr_padded_dim(d), nt, k)) return prefilter_layout(ctx, nq, nt, d, k).total;
     return knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
 }
 

@@ -254,11 +254,9 @@ int main(int argc, char **argv) {
         printf("rc=%d lines=%lld parts=%lld bad_rc=%d\n", rc, (long long)lines, (long long)(l1 + lines2), rc_bad);
         return rc ? 1 : 0;
     }
-    if (cmd == "plan-print" && (argc == 7 || argc == 8)) {  // host_san plan-print NQ NT D K SHAPE [SYM]  (shape -1: the exact mode's choice)
-        const KnnPlan p = knn_plan(256, atoll(argv[2]), atoll(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]),
-                                   argc == 8 && atoi(argv[7]) != 0);
-        printf("shape=%d nqb=%d nseg=%d nslot=%d sym=%d cohort=%d queues=%d tiles:", p.shape, p.nqb, p.nseg, p.nslot, p.sym,
-               p.cohort, p.queues);
+    if (cmd == "plan-print" && argc == 7) {  // host_san plan-print NQ NT D K SHAPE  (shape -1: the exact mode's choice)
+        const KnnPlan p = knn_plan(256, atoll(argv[2]), atoll(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+        printf("shape=%d nqb=%d nseg=%d cohort=%d queues=%d tiles:", p.shape, p.nqb, p.nseg, p.cohort, p.queues);
         for (int i = 0; i < p.nseg; ++i) printf(" %d", (p.segs.b[i + 1] - p.segs.b[i]) / 32);
         printf(" bytes=%zu\n", p.total_bytes);
         return 0;

@@ -1,14 +1,15 @@
 """BASELINE.json configs 4 and 5 on the one GPU a test box has: ONE RANK'S SHARE of the 8-GPU runs through the
-device API (fdr_normalize_dev + fdr_knn_dev, what distributed.ShardedPipeline calls after the all-gather).
+device API (fdr_embed_dev, fdr_normalize_dev + fdr_knn_dev: what distributed.ShardedPipeline calls).
 
-  config 4: 10 M rows, d = 128, k = 20, rows sharded 1.25 M per GPU  -> queries = rows [0, 1.25 M) of 10 M targets
-  config 5: 10 M reads doubled (20 M rows), d = 256, k = 50          -> the same shape at 1 M doubled rows
-            (20 M x 256 needs the node's other seven GPUs' worth of time, not of memory: see the workspace test)
+  config 4: 10 M reads, d = 128, k = 20, rows sharded 1.25 M per GPU   -> queries = rows [0, 1.25 M) of 10 M targets
+  config 5: 10 M reads doubled (20 M rows), d = 256, k = 50            -> queries = rows [0, 2.5 M) of 20 M targets
 
-The embeddings are made on the device (locus prototypes with a few non-zero components + per-read drop-outs:
-sparse rows, near-duplicates, exact duplicates, all-zero rows -- the structure of real projected k-mer
-profiles) because a 10 M-row CSR takes the host longer to synthesise than the GPU needs to search it.  Parity:
-a sample of query rows against the exact CPU oracle over ALL targets, bit for bit, + whole-result properties."""
+Both at FULL per-rank size from the real generator (tests/_rank_share.py: synth CSR, F = 25 M projection tables,
+embed of every row on this GPU in pieces, then the rank's k-NN), checked against the CPU oracle with the targets
+streamed back from HBM in pieces.  The smaller cases below use device-made embeddings (locus prototypes with a few
+non-zero components + per-read drop-outs: sparse rows, near-duplicates, exact duplicates, all-zero rows) for shapes
+the two configs do not cover.  Parity: a sample of query rows against the exact CPU oracle over ALL targets, bit
+for bit, + whole-result properties."""
 import numpy as np
 import pytest
 
@@ -71,16 +72,38 @@ def _check_rank_share(ctx, oracle, E, nq, k, sample=256):
     return ut, uq
 
 
-def test_config4_one_rank_share_10m_targets(ctx, oracle):
-    """1.25 M query rows against 10 M targets, d = 128, k = 20: what each of the 8 ranks of config 4 runs after
-    the all-gather (22 target segments of <= 2^19 rows, duplicate-row classes over the full target set)."""
+def _real_rank_share(ctx, oracle, tag, **kw):
+    import json
+    import os
+    import sys
+    from _rank_share import assert_rank_share, run_rank_share
     ctx.set_knn_mode("auto")
     ctx.set_dedup_mode("auto")
-    E = _device_embeddings(10_000_000, 128, nnz=6, loci=4_000_000, seed=4)
-    ut, uq = _check_rank_share(ctx, oracle, E, 1_250_000, 20)
-    assert 20 <= ut <= 10_000_000 and uq <= 1_250_000
-    launches, queues = ctx.last_prefilter_launches()
-    assert queues == 2 and launches > 100  # synchronised rounds of two workgroups per CU on two queues
+    info = run_rank_share(ctx, oracle, log=lambda *a: print("[%s]" % tag, *a, file=sys.stderr, flush=True), **kw)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):  # (the measured line of this run, for profiles/)
+        with open(os.path.join(out, "%s_rank_share.json" % tag), "w") as f:
+            f.write(json.dumps(info) + "\n")
+    assert_rank_share(info)
+    return info
+
+
+def test_config4_real_generator_one_rank_share_full_size(ctx, oracle):
+    """Config 4 as BASELINE states it, rank 0's share: synth(10 M reads) CSR -> projection tables at F = 25 M ->
+    embed (the block's E against orc_embed, bit for bit; the other ranks' blocks embedded on this GPU too) ->
+    1.25 M query rows against all 10 M rows, d = 128, k = 20."""
+    info = _real_rank_share(ctx, oracle, "config4", R=10_000_000, d=128, k=20, doubling=False)
+    assert info["n_features"] == 25_000_000 and info["query_rows"] == 1_250_016  # (blocks are multiples of 32 rows)
+    assert 20 <= info["unique_targets"] <= 10_000_000 and info["unique_queries"] <= 1_250_000
+    assert info["prefilter_queues"] == 2 and info["prefilter_launches"] > 30  # synchronised rounds, two queues
+
+
+def test_config5_real_generator_one_rank_share_full_size(ctx, oracle):
+    """Config 5 as BASELINE states it, one rank's share at full size: 10 M reads with fwd / rev doubling = 20 M
+    rows (39 target segments of 48), d = 256, k = 50 (K' = 58), 2.5 M query rows."""
+    info = _real_rank_share(ctx, oracle, "config5", R=10_000_000, d=256, k=50, doubling=True, sample=128)
+    assert info["rows"] == 20_000_000 and info["query_rows"] == 2_500_000
+    assert info["unique_targets"] <= 20_000_000
 
 
 def test_config5_shape_doubled_rows_d256_k50(ctx, oracle):
