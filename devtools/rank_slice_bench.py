@@ -53,13 +53,16 @@ for G in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1,
         nu = eng.knn_classes(Ehat, zero, n, d, k, nq_max)
         if nu > 0:
             Su = -(-nu // G)
-            iu = torch.zeros((Su * G, k), dtype=torch.int32, device=dev)
-            du = torch.zeros((Su * G, k), dtype=torch.float32, device=dev)
+            iu = torch.zeros((Su, k), dtype=torch.int32, device=dev)
+            du = torch.zeros((Su, k), dtype=torch.float32, device=dev)
+            pu = torch.zeros((Su * G, 2 * k), dtype=torch.int32, device=dev)
 
             def unique_step():
                 eng.knn_classes(Ehat, zero, n, d, k, nq_max)
                 eng.knn_unique(0, min(nu, Su), k, iu, du)
-                return eng.knn_expand(lo, hi - lo, k, iu, du)
+                pu[:Su, :k] = iu
+                pu[:Su, k:] = du.view(torch.int32)
+                return eng.knn_expand(lo, hi - lo, k, pu)
             unique_step()
             torch.cuda.synchronize(dev)
             ctx.timing(True)

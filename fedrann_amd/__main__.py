@@ -94,6 +94,7 @@ def build_parser():
                    help="With --devices: nccl (= RCCL over xGMI; one GPU per process) or gloo (processes may "
                         "share a GPU: one-GPU rehearsal of the sharded path).")
     g.add_argument("--rank-worker", action="store_true", default=False, help=argparse.SUPPRESS)
+    g.add_argument("--stage1-worker", action="store_true", default=False, help=argparse.SUPPRESS)
     return p
 
 
@@ -246,79 +247,175 @@ def run_fedrann_pipeline(*, output_dir, embedding_dimension, nndescent_n_trees,
     logger.info("Pipeline completed.")
 
 
+def doubled_names(name_off, name_buf):
+    """(name_off, names) of the R records -> the same for the 2R doubled rows (row 2r and 2r + 1 carry record r's
+    id), as fdr_overlaps_write takes them.  Ids that are not valid UTF-8 follow the reference's rule
+    (feature_extraction.py:125-128) through the str path."""
+    from . import _lib
+    from .feature_extraction import _decode_names
+    raw = name_buf.tobytes()
+    if not raw.isascii():
+        try:
+            raw.decode("utf-8")
+        except UnicodeDecodeError:
+            return _lib.pack_names([n for n in _decode_names(name_off, name_buf) for _ in (0, 1)])
+    lens = np.diff(name_off)
+    off2 = np.zeros(2 * lens.size + 1, dtype=np.int64)
+    np.cumsum(np.repeat(lens, 2), out=off2[1:])
+    src = np.repeat(name_off[:-1], 2)  # first byte of every doubled row's id in name_buf
+    pos = np.arange(int(off2[-1]), dtype=np.int64) - np.repeat(off2[:-1], np.repeat(lens, 2)) + np.repeat(src, np.repeat(lens, 2))
+    return off2, np.ascontiguousarray(name_buf[pos])
+
+
+def load_rank_inputs(args, output_dir, rank, world):
+    """What ONE rank of `--devices` needs on the host: the projection matrix, ITS row block of the read x feature
+    CSR (1 / world of the matrix: the ranged native loader for output.bin; a feature_matrix.npz is inflated whole
+    and sliced, scipy's format has no random access) and the names / strands of all rows for the writer.
+    Returns (n_rows, lo, hi, indptr, indices, n_features, P, name_off, names, strands)."""
+    from . import _lib
+    from .distributed import local_csr, shard_rows
+    if args.kmer_searcher_output:
+        from .precompute import read_kmer_counts
+        n_features = 2 * int(read_kmer_counts(args.kmer_library).size)  # (count_kmers.py:148)
+        P, n_features = get_precompute_matrix(n_components=args.embedding_dimension, counter_file=args.kmer_library,
+                                              n_features=n_features)
+        R, _, _, _, _ = _lib.kmer_output_load_range(args.kmer_searcher_output, n_features, 0, 0, with_names=False)
+        n = 2 * R
+        _, blocks = shard_rows(n, world)
+        lo, hi = blocks[rank]
+        try:
+            _, ip, ix, name_off, name_buf = _lib.kmer_output_load_range(
+                args.kmer_searcher_output, n_features, lo // 2, hi // 2,
+                n_threads=global_variables.threads if global_variables.threads > 1 else 0)
+        except _lib.FedrannHipError as e:
+            if "output.bin:" in str(e):  # format errors keep the reference's exception type
+                raise ValueError(str(e).split("output.bin:", 1)[1].strip()) from None
+            raise
+        name_off, names = doubled_names(name_off, name_buf)
+        strands = np.tile(np.array([0, 1], dtype=np.uint8), R)
+        if args.save_feature_matrix and rank == 0:  # (the whole matrix, once)
+            from .feature_extraction import build_feature_csr
+            fip, fix, _, _ = build_feature_csr(args.kmer_searcher_output, n_features)
+            save_feature_matrix_npz(join(output_dir, "feature_matrix.npz"), fip, fix, n_features)
+            del fip, fix
+    else:
+        indptr, indices, n_features = load_feature_matrix_npz(args.feature_matrix)
+        P = build_precompute_matrix(_load_counts(args.kmer_counts), args.embedding_dimension, n_features=n_features)
+        n = indptr.size - 1
+        _, blocks = shard_rows(n, world)
+        lo, hi = blocks[rank]
+        if args.save_feature_matrix and rank == 0:
+            save_feature_matrix_npz(join(output_dir, "feature_matrix.npz"), indptr, indices, n_features)
+        ip, ix = local_csr(indptr, indices, lo, hi)
+        del indptr, indices
+        read_names, strand_list = _load_names(args.read_names, n)
+        name_off, names = _lib.pack_names(read_names)
+        strands = np.asarray(strand_list, dtype=np.uint8)
+    return n, lo, hi, ip, ix, n_features, P, name_off, names, strands
+
+
 def run_rank_worker(args, output_dir, temp_dir):
-    """One rank of `--devices`: RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / FEDRANN_DEVICE come from
-    the parent.  Rank 0 runs stage 1 if reads were given; every rank then embeds its row block, the
-    normalised blocks are all-gathered, every rank searches its rows against all rows
-    (distributed.ShardedPipeline) and writes temp/overlaps.rank<r>.tsv."""
+    """One rank of `--devices`: RANK / WORLD_SIZE / FEDRANN_DEVICE / FEDRANN_RENDEZVOUS come from the parent, and
+    so does stage 1's output (the parent runs it in a child of its own before it starts the ranks).  A rank
+    loads ITS rows of the feature matrix, embeds them, the normalised blocks are all-gathered, it searches its
+    rows against all rows (distributed.ShardedPipeline) and writes temp/overlaps.rank<r>.tsv."""
+    import datetime
     import torch
     import torch.distributed as dist
     from . import _lib
-    from .distributed import HipEngine, ShardedPipeline, local_csr
+    from .distributed import HipEngine, ShardedPipeline
     from .feature_extraction import _projection_csr
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     device = torch.device("cuda", int(os.environ["FEDRANN_DEVICE"]))
     torch.cuda.set_device(device)
+    # rendezvous through a file in temp/ (no port to lose to another process); the host stages between two
+    # collectives (loading a rank's rows of a 10 M-read matrix, writing its part of overlaps.tsv) may take long
+    kw = dict(init_method="file://" + os.environ["FEDRANN_RENDEZVOUS"], rank=rank, world_size=world,
+              timeout=datetime.timedelta(hours=12))
     if args.dist_backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group("nccl", device_id=device, **kw)
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    have_ks = bool(args.kmer_searcher_output)
-    if args.input and not have_ks and not args.feature_matrix:
-        ks_path = join(temp_dir, "kmer_searcher", "output.bin")
-        if rank == 0:
-            if args.kmer_library:
-                logger.info("--- 1b. k-mer search on the GPU ---")
-                _gpu_kmer_search(args.input, args.kmer_library, args.kmer_size, temp_dir)
-            else:
-                from .count_kmers import run_kmer_searcher
-                logger.info("--- 1. Counter kmers (GPU) ---")
-                run_kmer_searcher(input_path=args.input, k=args.kmer_size, sample_fraction=args.kmer_sample_fraction,
-                                  min_multiplicity=args.kmer_min_multiplicity)
-        dist.barrier()
-        args.kmer_searcher_output = ks_path
-        if not args.kmer_library:
-            args.kmer_library = join(temp_dir, "fwd_kmer_library.fasta")
-    indptr, indices, n_features, P, read_names, strands = load_inputs(
-        output_dir=output_dir, embedding_dimension=args.embedding_dimension,
-        save_feature_matrix=args.save_feature_matrix, kmer_searcher_output=args.kmer_searcher_output,
-        kmer_library=args.kmer_library, feature_matrix=args.feature_matrix, kmer_counts=args.kmer_counts,
-        read_names_path=args.read_names, save=rank == 0)
-    n, k = indptr.size - 1, args.nndescent_n_neighbors
+        dist.init_process_group("gloo", **kw)
+    n, lo, hi, ip, ix, n_features, P, name_off, names, strands = load_rank_inputs(args, output_dir, rank, world)
+    k = args.nndescent_n_neighbors
     ctx = _lib.Context(device.index)
     Pc = _projection_csr(P)
     ctx.projection_load(Pc.indptr, Pc.indices, Pc.data, n_features, args.embedding_dimension)
     pipe = ShardedPipeline(HipEngine(ctx, device), n, args.embedding_dimension, k, rank=rank, world_size=world,
                            device=device)
-    ip, ix = local_csr(indptr, indices, pipe.lo, pipe.hi)
+    assert (pipe.lo, pipe.hi) == (lo, hi)
+    logger.debug("rank %d of %d holds rows [%d, %d) of %d: %d column ids", rank, world, lo, hi, n, ix.size)
     ip, ix = ctx.csr_compact(ip, ix)
-    del indptr, indices
     if rank == 0:
         logger.info("--- 4. Nearest Neighbors Search (%d rows over %d GPUs) ---", n, world)
     idx, dst, _ = pipe.step(torch.from_numpy(ip).to(device), torch.from_numpy(ix).to(device))
     torch.cuda.synchronize(device)
     part = join(temp_dir, "overlaps.rank%d.tsv" % rank)
-    rows = write_overlaps(part, idx.cpu().numpy(), dst.cpu().numpy(), read_names, strands, row0=pipe.lo,
-                          header=rank == 0)
-    logger.debug("rank %d: rows [%d, %d), %d overlap rows", rank, pipe.lo, pipe.hi, rows)
+    rows = _lib.overlaps_write(part, idx.cpu().numpy(), dst.cpu().numpy(), name_off, names, strands, row0=lo,
+                               header=rank == 0,
+                               n_threads=global_variables.threads if global_variables.threads > 1 else 0)
+    logger.debug("rank %d: rows [%d, %d), %d overlap rows", rank, lo, hi, rows)
     dist.barrier()
     dist.destroy_process_group()
     ctx.close()
 
 
-def launch_rank_workers(argv, devices, output_dir, temp_dir, keep_intermediates):
+def run_stage1_worker(args, temp_dir):
+    """Stage 1 of a `--devices` run (k-mer counting / sampling / search on the first GPU), as a child of its own
+    that has exited before the ranks start: no rank waits inside a collective while it runs."""
+    if args.kmer_library:
+        logger.info("--- 1b. k-mer search on the GPU ---")
+        _gpu_kmer_search(args.input, args.kmer_library, args.kmer_size, temp_dir)
+    else:
+        from .count_kmers import run_kmer_searcher
+        logger.info("--- 1. Counter kmers (GPU) ---")
+        run_kmer_searcher(input_path=args.input, k=args.kmer_size, sample_fraction=args.kmer_sample_fraction,
+                          min_multiplicity=args.kmer_min_multiplicity)
+
+
+def launch_rank_workers(argv, args, devices, output_dir, temp_dir, keep_intermediates):
     """The parent of `--devices`: no GPU call here (a process that has initialised the GPU must not start
-    others on this pool, and the children own the devices).  Children = this module with --rank-worker."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    others on this pool, and the children own the devices).  Children = this module with --stage1-worker
+    (once, when reads were given) and --rank-worker (one per device)."""
+    import time
+    argv = list(argv)
+    if args.input and not args.kmer_searcher_output and not args.feature_matrix:
+        env = dict(os.environ, FEDRANN_DEVICE=str(devices[0]))
+        rc = subprocess.call([sys.executable, "-m", "fedrann_amd"] + argv + ["--stage1-worker"], env=env)
+        if rc:
+            raise SystemExit("stage 1 failed: exit code %d" % rc)
+        argv += ["--kmer-searcher-output", join(temp_dir, "kmer_searcher", "output.bin")]
+        if not args.kmer_library:
+            argv += ["--kmer-library", join(temp_dir, "fwd_kmer_library.fasta")]
+    rendezvous = join(temp_dir, "rendezvous.%d" % os.getpid())
+    if os.path.exists(rendezvous):
+        os.remove(rendezvous)
     procs = []
     for rank, dev in enumerate(devices):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FEDRANN_DEVICE=str(dev))
-        procs.append(subprocess.Popen([sys.executable, "-m", "fedrann_amd"] + list(argv) + ["--rank-worker"], env=env))
-    codes = [p.wait() for p in procs]
+                   FEDRANN_DEVICE=str(dev), FEDRANN_RENDEZVOUS=rendezvous)
+        procs.append(subprocess.Popen([sys.executable, "-m", "fedrann_amd"] + argv + ["--rank-worker"], env=env))
+    # poll all ranks: the first failure ends the others (they would sit in a collective until its timeout)
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    if os.path.exists(rendezvous):
+        os.remove(rendezvous)
     if any(codes):
         raise SystemExit("rank worker(s) failed: exit codes %s" % codes)
     out = join(output_dir, "overlaps.tsv")
@@ -362,7 +459,7 @@ def main(argv=None):
     global_variables.seed = args.seed
     check_limits(args.embedding_dimension, args.nndescent_n_neighbors)  # before any work (the library would
     # only refuse them after stages 1-3)
-    if args.device is not None and not args.rank_worker:
+    if args.device is not None and not (args.rank_worker or args.stage1_worker):
         os.environ["FEDRANN_DEVICE"] = str(args.device)
     output_dir = abspath(args.output_dir)
     os.makedirs(output_dir, exist_ok=True)
@@ -373,6 +470,8 @@ def main(argv=None):
     global_variables.temp_dir = temp_dir
     have_ks = bool(args.kmer_searcher_output)
     have_fm = bool(args.feature_matrix)
+    if args.rank_worker and have_ks:
+        args.input = None  # (stage 1 has run: the parent passes its output next to the user's arguments)
     if sum((bool(args.input), have_ks, have_fm)) != 1:
         raise SystemExit(
             "give exactly one of -i reads, -i reads + --kmer-library, --kmer-searcher-output + --kmer-library, "
@@ -383,12 +482,14 @@ def main(argv=None):
         raise SystemExit("--feature-matrix needs --kmer-counts")
     if args.rank_worker:
         return run_rank_worker(args, output_dir, temp_dir)
+    if args.stage1_worker:
+        return run_stage1_worker(args, temp_dir)
     logger.info("FEDRANN (MI355X hot path) version: %s", __version__)
     logger.debug("Parameters: %s", args)
     if args.devices:
         devices = [int(x) for x in args.devices.split(",") if x.strip() != ""]
         if len(devices) > 1:
-            return launch_rank_workers(argv, devices, output_dir, temp_dir, args.keep_intermediates)
+            return launch_rank_workers(argv, args, devices, output_dir, temp_dir, args.keep_intermediates)
         if devices:
             os.environ["FEDRANN_DEVICE"] = str(devices[0])
     if args.input and args.kmer_library and not have_ks and not have_fm:

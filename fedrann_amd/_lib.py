@@ -19,7 +19,7 @@ SYMBOLS = (
     "fdr_kmer_output_load", "fdr_kmer_search", "fdr_kmer_search_indices", "fdr_kmer_count",
     "fdr_kmer_count_fetch", "fdr_set_kmer_count_block", "fdr_last_kmer_count_blocks", "fdr_csr_compact", "fdr_host_register", "fdr_host_unregister",
     "fdr_overlaps_write", "fdr_last_prefilter_launches", "fdr_knn_classes_dev", "fdr_knn_unique_dev",
-    "fdr_knn_expand_dev",
+    "fdr_knn_expand_dev", "fdr_kmer_output_scan_range", "fdr_kmer_output_load_range",
 )
 FDR_MAX_K = 64
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
@@ -83,7 +83,7 @@ def load_library():
     L.fdr_knn_dev.argtypes = [vp, vp, vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, vp, sz, vp]
     L.fdr_knn_classes_dev.argtypes = [vp, vp, vp, i64, i32, i32, i64, vp, sz, vp, ctypes.POINTER(i32)]
     L.fdr_knn_unique_dev.argtypes = [vp, i64, i64, vp, vp, vp]
-    L.fdr_knn_expand_dev.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.fdr_knn_expand_dev.argtypes = [vp, i64, i64, i64, vp, vp, i64, vp, vp, vp]
     L.fdr_last_uncertified.argtypes = [vp]
     L.fdr_set_knn_mode.argtypes = [vp, ctypes.c_int]
     L.fdr_set_dedup_mode.argtypes = [vp, ctypes.c_int]
@@ -92,6 +92,8 @@ def load_library():
     p64 = ctypes.POINTER(ctypes.c_int64)
     L.fdr_kmer_output_scan.argtypes = [ctypes.c_char_p, p64, p64, p64]
     L.fdr_kmer_output_load.argtypes = [ctypes.c_char_p, i64, i32, i64, i64, i64, vp, vp, vp, vp]
+    L.fdr_kmer_output_scan_range.argtypes = [ctypes.c_char_p, i64, i64, p64, p64, p64]
+    L.fdr_kmer_output_load_range.argtypes = [ctypes.c_char_p, i64, i32, i64, i64, i64, i64, i64, vp, vp, vp, vp]
     L.fdr_csr_compact.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32]
     L.fdr_host_register.argtypes = [vp, vp, sz]
     L.fdr_host_unregister.argtypes = [vp, vp]
@@ -142,6 +144,34 @@ def kmer_output_load(path, n_features, n_threads=0):
     if rc != 0:
         raise FedrannHipError("fdr_kmer_output_load failed (%d): %s" % (rc, L.fdr_last_error().decode()))
     return indptr, indices, name_off, names
+
+
+def kmer_output_load_range(path, n_features, rec_lo, rec_hi, n_threads=0, with_names=True):
+    """Rows of the records [rec_lo, rec_hi) of output.bin (rec_hi = None: to the end) -- a rank's block of a
+    row-sharded run -- as (n_records of the file, indptr int64 [2 (hi - lo) + 1] rebased to 0, indices int32,
+    name_off, names of ALL records or (None, None))."""
+    L = load_library()
+    bpath = os.fsencode(path)
+    R, nnz, nb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    rc = L.fdr_kmer_output_scan(bpath, ctypes.byref(R), ctypes.byref(nnz), ctypes.byref(nb))
+    if rc != 0:
+        raise FedrannHipError("fdr_kmer_output_scan failed (%d): %s" % (rc, L.fdr_last_error().decode()))
+    lo = max(0, min(int(rec_lo), R.value))
+    hi = R.value if rec_hi is None else max(lo, min(int(rec_hi), R.value))
+    rc = L.fdr_kmer_output_scan_range(bpath, lo, hi, ctypes.byref(R), ctypes.byref(nnz), ctypes.byref(nb))
+    if rc != 0:
+        raise FedrannHipError("fdr_kmer_output_scan_range failed (%d): %s" % (rc, L.fdr_last_error().decode()))
+    indptr = np.empty(2 * (hi - lo) + 1, dtype=np.int64)
+    indices = np.empty(2 * nnz.value, dtype=np.int32)
+    name_off = np.empty(R.value + 1, dtype=np.int64) if with_names else None
+    names = np.empty(nb.value, dtype=np.uint8) if with_names else None
+    rc = L.fdr_kmer_output_load_range(bpath, int(n_features), int(n_threads), R.value, lo, hi, nnz.value, nb.value,
+                                      indptr.ctypes.data, indices.ctypes.data,
+                                      name_off.ctypes.data if with_names else None,
+                                      names.ctypes.data if with_names and names.size else None)
+    if rc != 0:
+        raise FedrannHipError("fdr_kmer_output_load_range failed (%d): %s" % (rc, L.fdr_last_error().decode()))
+    return R.value, indptr, indices, name_off, names
 
 
 def pack_names(read_names):
@@ -405,9 +435,9 @@ class Context:
         self._check(self._L.fdr_knn_unique_dev(self._h, int(u_lo), int(u_hi), d_idx_u, d_dist_u, stream or None),
                     "fdr_knn_unique_dev")
 
-    def knn_expand_dev(self, q0, nq, t_base, d_idx_u_all, d_dist_u_all, d_idx, d_dist, stream=0):
+    def knn_expand_dev(self, q0, nq, t_base, d_idx_u_all, d_dist_u_all, d_idx, d_dist, stream=0, u_row_stride=0):
         self._check(self._L.fdr_knn_expand_dev(self._h, int(q0), int(nq), int(t_base), d_idx_u_all, d_dist_u_all,
-                                               d_idx, d_dist, stream or None), "fdr_knn_expand_dev")
+                                               int(u_row_stride), d_idx, d_dist, stream or None), "fdr_knn_expand_dev")
 
 
 _default_ctx = None

@@ -558,20 +558,21 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.off_thetac = o;   o += align256((size_t)L.rchunk * 4);
     L.off_cnt = o;      o += align256((size_t)L.rchunk * 4);
     L.off_rcand = o;    o += align256((size_t)L.rchunk * RANGE_CAP * 4);
-    L.ordered = pp.cohort > 0;  // (the sizes at which the pass runs in synchronised rounds)
+    L.ordered = pp.cohort > 0 || dev_env_int("FDR_KNN_ORDERED", 0) != 0;  // (the sizes at which the pass runs in synchronised rounds)
     L.off_okeys = L.off_okeys_s = L.off_ovals = L.off_perm_t = L.off_perm_q = L.off_ho_t = L.off_ho_q = 0;
     L.off_otmp = L.otmp_bytes = 0;
     if (L.ordered) {
-        L.off_okeys = o;    o += align256((size_t)nt * 8);
-        L.off_okeys_s = o;  o += align256((size_t)nt * 8);
-        L.off_ovals = o;    o += align256((size_t)nt * 4);
+        const size_t nmax = (size_t)std::max(nq, nt);  // (the keys / sort scratch serve the targets, then the queries)
+        L.off_okeys = o;    o += align256(nmax * 8);
+        L.off_okeys_s = o;  o += align256(nmax * 8);
+        L.off_ovals = o;    o += align256(nmax * 4);
         L.off_perm_t = o;   o += align256((size_t)nt * 4);
         L.off_perm_q = o;   o += align256((size_t)nq * 4);
         L.off_ho_t = o;     o += align256((size_t)nt * dp * 2);
         L.off_ho_q = o;     o += align256((size_t)nq * dp * 2);
         size_t t_sort = 0;
         (void)rocprim::radix_sort_pairs(nullptr, t_sort, (u64 *)nullptr, (u64 *)nullptr, (int *)nullptr, (int *)nullptr,
-                                        (size_t)nt, 0, 40, (hipStream_t) nullptr);
+                                        nmax, 0, 40, (hipStream_t) nullptr);
         L.otmp_bytes = align256(t_sort);
         L.off_otmp = o;     o += L.otmp_bytes;
     }
@@ -694,7 +695,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     // Ordered scan (knn_order.inc): rows by chunk mask, fp16 copies in that order
     OrderArgs ord = {nullptr, nullptr};
     const _Float16 *p1_q = d_hq, *p1_t = d_ht;  // what the candidate pass streams
-    if (L.ordered && p.cohort > 0) {
+    if (L.ordered) {
         u64 *okeys = reinterpret_cast<u64 *>(ws + L.off_okeys), *okeys_s = reinterpret_cast<u64 *>(ws + L.off_okeys_s);
         int *ovals = reinterpret_cast<int *>(ws + L.off_ovals);
         int *perm_t = reinterpret_cast<int *>(ws + L.off_perm_t), *perm_q = reinterpret_cast<int *>(ws + L.off_perm_q);
@@ -784,6 +785,8 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             if (sh.nw == 8) FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512);
             else FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
         } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
+        else if (dp == 256 && sh.wps == 2 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 2, 2);
+        else if (dp == 256 && sh.wps == 2) FDR_LAUNCH_PRE(256, 1, 4, 2, 2);
         else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
         else FDR_LAUNCH_PRE(512, 1, 4, 2, 2);
 #undef FDR_LAUNCH_PRE3
@@ -923,6 +926,7 @@ struct DedupLayout {
         off_distu, off_tmp, tmp_bytes, total;
 };
 
+#define FDR_DEDUP_PROBE_BELOW (1 << 18)
 static bool knn_dedup_wanted(const fdr_ctx *ctx, int64_t nq, int64_t nt) {
     if (ctx->dedup_mode != FDR_DEDUP_AUTO) return ctx->dedup_mode != FDR_DEDUP_OFF;
     return nt >= 8192 && nq >= 1024;  // (from the size at which the prefilter mode engages)
@@ -1005,7 +1009,9 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     hipLaunchKernelGGL(hash_rows_kernel, dim3(g16), dim3(256), 0, st, d_That, n, dp, hash, idx);
     HIP_TRY(hipGetLastError());
     const bool always = ctx->dedup_mode == FDR_DEDUP_FORCE;  // expand even without duplicates (tests)
-    if (!always) {
+    // From 2^18 targets the sort and the tables (< 1 ms at 1 M rows) are noise next to the search (~ n^2): no probe,
+    // no read-back for it; the decision falls on the exact unique counts below.
+    if (!always && nt < FDR_DEDUP_PROBE_BELOW) {
         // a hash-table probe (~15 us) tells whether enough rows repeat to pay for the sort and the tables;
         // the table borrows the (still unused) unique-row buffer
         unsigned tsize = 1024;
@@ -1083,7 +1089,7 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)((nq + xw - 1) / xw)), dim3(64 * xw), (size_t)xw * k * k * 8, st, q0, (int)nq, k, (int)t_base,
                        (const int *)cls, (const int *)uofc, (const int *)uqpos, (const int *)idx_u,
                        (const float *)dist_u, (const int *)cofu, (const int *)cstart, (const int *)idx_s, d_idx,
-                       d_dist);
+                       d_dist, k);
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
 }
@@ -1130,22 +1136,9 @@ FDR_EXPORT int fdr_knn_classes_dev(fdr_ctx *ctx, const float *d_That, const uint
     if (trc) return trc;
     hipLaunchKernelGGL(hash_rows_kernel, dim3(g16), dim3(256), 0, st, d_That, n, dp, hash, idx);
     HIP_TRY(hipGetLastError());
-    if (ctx->dedup_mode != FDR_DEDUP_FORCE) {  // (the same probe as launch_knn: enough repeats to pay for the tables?)
-        unsigned tsize = 1024;
-        while (tsize < 2u * (unsigned)n && tsize < (1u << 30)) tsize <<= 1;
-        if ((size_t)tsize * 8 + 256 <= (size_t)nt * dp * 4) {
-            u64 *table = reinterpret_cast<u64 *>(U);
-            int *d_cnt = reinterpret_cast<int *>(table + tsize);
-            HIP_TRY(hipMemsetAsync(table, 0, (size_t)tsize * 8 + 4, st));
-            hipLaunchKernelGGL(dedup_probe_kernel, dim3(g1), dim3(256), 0, st, (const u64 *)hash, n, table, tsize - 1,
-                               d_cnt);
-            HIP_TRY(hipGetLastError());
-            int dups = 0;
-            HIP_TRY(hipMemcpyAsync(&dups, d_cnt, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if ((double)dups < 0.05 * (double)n) return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
-        }
-    }
+    // No hash-table probe here (launch_knn's shortcut for small sets): its count depends on the order in which
+    // the table fills, and every rank of a row-sharded run must take the SAME decision from the same gathered
+    // rows or their collectives no longer match.  The exact unique count after the sort is deterministic.
     size_t tb = L.tmp_bytes;
     HIP_TRY(rocprim::radix_sort_pairs(tmp, tb, hash, hash_s, idx, idx_s, (size_t)n, 0, 64, st));
     hipLaunchKernelGGL(mark_class_starts_kernel, dim3(g1), dim3(256), 0, st, d_That, n, dp, (const u64 *)hash_s,
@@ -1162,7 +1155,9 @@ FDR_EXPORT int fdr_knn_classes_dev(fdr_ctx *ctx, const float *d_That, const uint
     int nu = 0;
     HIP_TRY(hipMemcpyAsync(&nu, cid + (n - 1), 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (nu < k) return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);  // (fewer unique rows than neighbours asked for)
+    // (fewer unique rows than neighbours asked for; or too few repeats to pay: the rule of launch_knn, on exact counts)
+    if (nu < k || (ctx->dedup_mode != FDR_DEDUP_FORCE && (double)nu * (double)nu > 0.9 * (double)nt * (double)nt))
+        return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
     hipLaunchKernelGGL(gather_unique_rows_kernel, dim3(g16), dim3(256), 0, st, d_That, d_tzero, n, dp,
                        (const int *)isrep, (const int *)upos, U, uzero);
     HIP_TRY(hipGetLastError());
@@ -1204,7 +1199,8 @@ FDR_EXPORT int fdr_knn_unique_dev(fdr_ctx *ctx, int64_t u_lo, int64_t u_hi, int3
 }
 
 FDR_EXPORT int fdr_knn_expand_dev(fdr_ctx *ctx, int64_t q0, int64_t nq, int64_t t_base, const int32_t *d_idx_u_all,
-                                  const float *d_dist_u_all, int32_t *d_idx, float *d_dist, void *stream) {
+                                  const float *d_dist_u_all, int64_t u_row_stride, int32_t *d_idx, float *d_dist,
+                                  void *stream) {
     int rc = use_device(ctx);
     if (rc) return rc;
     if (!ctx->cls.valid) return fail(FDR_E_STATE, "knn_expand: no classes (call fdr_knn_classes_dev first)");
@@ -1213,6 +1209,8 @@ FDR_EXPORT int fdr_knn_expand_dev(fdr_ctx *ctx, int64_t q0, int64_t nq, int64_t 
     if (!d_idx_u_all || !d_dist_u_all || !d_idx || !d_dist) return fail(FDR_E_ARG, "knn_expand: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int k = ctx->cls.k;
+    if (u_row_stride == 0) u_row_stride = k;
+    if (u_row_stride < k || u_row_stride > 0x7fffffffll) return fail(FDR_E_ARG, "knn_expand: bad row stride");
     const DedupLayout L = dedup_layout(ctx, ctx->cls.nq_max, ctx->cls.nt, ctx->cls.d, k);
     char *ws = static_cast<char *>(ctx->cls.ws);
     int trc = timing_begin(ctx, FDR_KERNEL_KNN_DEDUP, st);
@@ -1221,7 +1219,8 @@ FDR_EXPORT int fdr_knn_expand_dev(fdr_ctx *ctx, int64_t q0, int64_t nq, int64_t 
     hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)((nq + xw - 1) / xw)), dim3(64 * xw), (size_t)xw * k * k * 8, st, (int)q0, (int)nq, k,
                        (int)t_base, (const int *)(ws + L.off_cls), (const int *)(ws + L.off_uofc), (const int *)nullptr,
                        (const int *)d_idx_u_all, d_dist_u_all, (const int *)(ws + L.off_cofu),
-                       (const int *)(ws + L.off_cstart), (const int *)(ws + L.off_idx_s), d_idx, d_dist);
+                       (const int *)(ws + L.off_cstart), (const int *)(ws + L.off_idx_s), d_idx, d_dist,
+                       (int)u_row_stride);
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
 }

@@ -82,12 +82,14 @@ class HipEngine:
         if u_hi > u_lo:
             self.ctx.knn_unique_dev(u_lo, u_hi, out_idx.data_ptr(), out_dst.data_ptr(), self._stream())
 
-    def knn_expand(self, q0, nq, k, idx_u_all, dst_u_all):
+    def knn_expand(self, q0, nq, k, packed_u_all):
+        """packed_u_all int32 [n_unique (padded), 2 k]: a unique row's k indices, then its k distance bit patterns."""
         idx = torch.empty((nq, k), dtype=torch.int32, device=self.device)
         dst = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         if nq:
-            self.ctx.knn_expand_dev(q0, nq, 0, idx_u_all.data_ptr(), dst_u_all.data_ptr(), idx.data_ptr(),
-                                    dst.data_ptr(), self._stream())
+            base = packed_u_all.data_ptr()
+            self.ctx.knn_expand_dev(q0, nq, 0, base, base + 4 * k, idx.data_ptr(), dst.data_ptr(), self._stream(),
+                                    u_row_stride=2 * k)
         return idx, dst
 
 
@@ -110,7 +112,7 @@ class ShardedPipeline:
             self.zero_loc = torch.zeros((S,), dtype=torch.uint8, device=self.device)
         else:
             self.Ehat_loc, self.zero_loc = self.Ehat_all, self.zero_all
-        self._iu = self._du = self._iu_loc = self._du_loc = None  # unique-row results (sized on first use)
+        self._pu = self._pu_loc = self._iu_loc = self._du_loc = None  # unique-row results (sized on first use)
 
     def step(self, indptr_local, indices_local):
         """indptr_local / indices_local: this rank's CSR rows (indptr rebased to 0) as tensors on
@@ -119,28 +121,34 @@ class ShardedPipeline:
         E = self.engine.embed(indptr_local, indices_local, nloc, self.d)
         self.engine.normalize(E, self.Ehat_loc, self.zero_loc)
         if self.world > 1:
+            # two collectives: the rows (S x DP fp32 per rank; the class layer compares whole rows, so the search
+            # cannot start on less) and the zero flags (S bytes; packing them behind a rank's rows would leave the
+            # gathered rows non-contiguous, and the kernels address row i at i * DP)
+            w = dist.all_gather_into_tensor(self.zero_all, self.zero_loc, group=self.group, async_op=True)
             dist.all_gather_into_tensor(self.Ehat_all, self.Ehat_loc, group=self.group)
-            dist.all_gather_into_tensor(self.zero_all, self.zero_loc, group=self.group)
+            w.wait()
         q0 = self.rank * self.S
         if self.world > 1 and hasattr(self.engine, "knn_classes"):
             # Split the UNIQUE rows over the ranks instead of searching every duplicate query row on every
             # rank that holds a member of its class: all ranks build the same class tables from the gathered
-            # rows, each searches its share of the unique rows, one more all-gather exchanges the shares
-            # (nu x k indices + distances), and each rank expands its own rows.
+            # rows (the decision to do so is a function of the exact unique count: the same on every rank), each
+            # searches its share of the unique rows, ONE more all-gather exchanges the shares (a unique row's k
+            # indices and k distance bit patterns side by side), and each rank expands its own rows.
             nq_max = -(-self.n // self.world)
             nu = self.engine.knn_classes(self.Ehat_all, self.zero_all, self.n, self.d, self.k, nq_max)
             if nu > 0:
-                Su = -(-nu // self.world)
+                Su, k = -(-nu // self.world), self.k
                 u_lo, u_hi = min(nu, self.rank * Su), min(nu, (self.rank + 1) * Su)
-                if self._iu is None or self._iu.shape[0] != Su * self.world:
-                    self._iu = torch.zeros((Su * self.world, self.k), dtype=torch.int32, device=self.device)
-                    self._du = torch.zeros((Su * self.world, self.k), dtype=torch.float32, device=self.device)
-                    self._iu_loc = torch.zeros((Su, self.k), dtype=torch.int32, device=self.device)
-                    self._du_loc = torch.zeros((Su, self.k), dtype=torch.float32, device=self.device)
-                self.engine.knn_unique(u_lo, u_hi, self.k, self._iu_loc, self._du_loc)
-                dist.all_gather_into_tensor(self._iu, self._iu_loc, group=self.group)
-                dist.all_gather_into_tensor(self._du, self._du_loc, group=self.group)
-                idx, dst = self.engine.knn_expand(q0, nloc, self.k, self._iu, self._du)  # (unique row u sits at row u)
+                if self._pu is None or self._pu.shape[0] != Su * self.world:
+                    self._pu = torch.zeros((Su * self.world, 2 * k), dtype=torch.int32, device=self.device)
+                    self._pu_loc = torch.zeros((Su, 2 * k), dtype=torch.int32, device=self.device)
+                    self._iu_loc = torch.zeros((Su, k), dtype=torch.int32, device=self.device)
+                    self._du_loc = torch.zeros((Su, k), dtype=torch.float32, device=self.device)
+                self.engine.knn_unique(u_lo, u_hi, k, self._iu_loc, self._du_loc)
+                self._pu_loc[:, :k] = self._iu_loc
+                self._pu_loc[:, k:] = self._du_loc.view(torch.int32)
+                dist.all_gather_into_tensor(self._pu, self._pu_loc, group=self.group)
+                idx, dst = self.engine.knn_expand(q0, nloc, k, self._pu)  # (unique row u sits at row u)
                 return idx, dst, E
         idx, dst = self.engine.knn(self.Ehat_all[q0:q0 + nloc], self.zero_all[q0:q0 + nloc], nloc,
                                    self.Ehat_all, self.zero_all, self.n, self.d, self.k)

@@ -129,18 +129,22 @@ int fdr_knn_dev(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64
  *   fdr_knn_classes_dev  builds the classes of the target set (the all-gathered Ehat: the same tables on
  *                        every rank) in the workspace -- fdr_knn_workspace_bytes(ctx, nq_max, nt, d, k) bytes,
  *                        nq_max = the most unique rows one later call will search -- and returns their number
- *                        in *n_unique_out; 0 = not worth it (small set, < 5 % repeats): use fdr_knn_dev.
+ *                        in *n_unique_out; 0 = not worth it (small set, or unique^2 > 0.9 rows^2): use fdr_knn_dev.
+ *                        The decision is a function of the exact unique count: the same on every rank.
  *   fdr_knn_unique_dev   k-NN of the unique rows [u_lo, u_hi) (ascending representative order) against all
  *                        unique rows: d_idx_u int32 [u_hi - u_lo, k] (unique-row numbers), d_dist_u float32.
  *   fdr_knn_expand_dev   given the results of ALL unique rows (the ranks' shares concatenated: [n_unique, k]),
  *                        the neighbours of the original rows [q0, q0 + nq): d_idx (+ t_base), d_dist [nq, k].
+ *                        u_row_stride = elements between two unique rows' results in d_idx_u_all / d_dist_u_all
+ *                        (0 = k; 2 k when a row's indices and distance bits travel side by side in ONE exchange:
+ *                        d_dist_u_all = (float *)(d_idx_u_all + k)).
  * The workspace must stay untouched between the three calls; fdr_knn_classes_dev synchronises the stream. */
 int fdr_knn_classes_dev(fdr_ctx *ctx, const float *d_That, const uint8_t *d_tzero, int64_t nt, int32_t d, int32_t k,
                         int64_t nq_max, void *d_workspace, size_t workspace_bytes, void *stream,
                         int32_t *n_unique_out);
 int fdr_knn_unique_dev(fdr_ctx *ctx, int64_t u_lo, int64_t u_hi, int32_t *d_idx_u, float *d_dist_u, void *stream);
 int fdr_knn_expand_dev(fdr_ctx *ctx, int64_t q0, int64_t nq, int64_t t_base, const int32_t *d_idx_u_all,
-                       const float *d_dist_u_all, int32_t *d_idx, float *d_dist, void *stream);
+                       const float *d_dist_u_all, int64_t u_row_stride, int32_t *d_idx, float *d_dist, void *stream);
 
 /* ---- per-kernel timing (bench.py's roofline figures) -----------------------------------------
  * With timing enabled every kernel launch is bracketed by its own hipEvent pair recorded on the
@@ -244,6 +248,17 @@ int fdr_last_kmer_count_blocks(fdr_ctx *ctx);
 int fdr_kmer_output_scan(const char *path, int64_t *n_records, int64_t *nnz, int64_t *name_bytes);
 int fdr_kmer_output_load(const char *path, int64_t n_features, int32_t n_threads, int64_t n_records, int64_t nnz,
                          int64_t name_bytes, int64_t *indptr, int32_t *indices, int64_t *name_off, char *names);
+/* The same for the records [rec_lo, rec_hi) only -- one rank's row block of a row-sharded run (rows 2 rec_lo ..
+ * 2 rec_hi of the matrix), so that G ranks hold 1/G of the CSR each instead of G copies of it:
+ *   fdr_kmer_output_scan_range: record count of the FILE, sum of index counts of the RANGE, id bytes of the file;
+ *   fdr_kmer_output_load_range: indptr int64 [2 (rec_hi - rec_lo) + 1] (rebased to 0), indices int32 [2 nnz_range];
+ *                               name_off int64 [R + 1] + names of ALL records (the writer names any target row),
+ *                               or name_off = NULL for no names. */
+int fdr_kmer_output_scan_range(const char *path, int64_t rec_lo, int64_t rec_hi, int64_t *n_records,
+                               int64_t *nnz_range, int64_t *name_bytes);
+int fdr_kmer_output_load_range(const char *path, int64_t n_features, int32_t n_threads, int64_t n_records,
+                               int64_t rec_lo, int64_t rec_hi, int64_t nnz_range, int64_t name_bytes, int64_t *indptr,
+                               int32_t *indices, int64_t *name_off, char *names);
 
 /* ---- overlaps.tsv writer (host only: no context, no GPU) ---------------------------------------------
  * Replaces get_output_dataframe + DataFrame.to_csv(sep="\t", index=False) (fedrann/__main__.py:261-300,

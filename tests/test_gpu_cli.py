@@ -179,6 +179,53 @@ def test_cli_devices_sharded_run_is_byte_identical(tmp_path):
     assert parts == ["overlaps.rank0.tsv", "overlaps.rank1.tsv", "overlaps.rank2.tsv"]
 
 
+def test_cli_devices_from_reads_runs_stage1_first_and_shards_the_host_side(tmp_path):
+    """`-i reads --devices a,b`: stage 1 runs in a child of its own BEFORE the ranks exist (nobody waits in a
+    collective meanwhile), every rank then loads only ITS rows of output.bin (the ranged native loader) and the
+    result is the single-GPU file byte for byte."""
+    import re
+    import subprocess
+    import sys
+    from fedrann_amd.synth import synth_sequences
+    k = 15
+    s = synth_sequences(500, genome_len=80_000, mean_len=2500, k=k, sample=0.05, seed=71)
+    rng = np.random.default_rng(5)
+    counts = rng.integers(2, 40, size=len(s["fwd"]))
+    lib = tmp_path / "fwd_kmer_library.fasta"
+    lib.write_bytes(b"".join(b">%d\n%s\n" % (int(c), x) for c, x in zip(counts, s["fwd"])))
+    fa = tmp_path / "reads.fasta"
+    fa.write_bytes(b"".join(b">%s\n%s\n" % (i, bytes(s["seqs"][s["seq_off"][j]:s["seq_off"][j + 1]]))
+                            for j, i in enumerate(s["ids"])))
+    base = ["-i", str(fa), "-k", str(k), "-n", "128", "--nndescent-n-neighbors", "20", "--kmer-library", str(lib)]
+    one = tmp_path / "one"
+    cli.main(["-o", str(one)] + base)
+    many = tmp_path / "many"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "fedrann_amd", "-o", str(many), "--devices", "0,0", "--dist-backend", "gloo"]
+                       + base, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (many / "overlaps.tsv").read_bytes() == (one / "overlaps.tsv").read_bytes()
+    held = [(int(m.group(1)), int(m.group(2))) for m in re.finditer(r"holds rows \[(\d+), (\d+)\) of 1000: (?:\d+) column ids", r.stderr)]
+    assert sorted(held) == [(0, 512), (512, 1000)]  # two ranks, 32-row-aligned blocks, each its own rows only
+
+
+def test_cli_devices_parent_ends_the_other_ranks_when_one_fails(tmp_path):
+    """A rank that dies (here: a device ordinal that does not exist) must not leave its siblings waiting in a
+    collective until the process group's timeout: the parent polls all children and ends the rest."""
+    import subprocess
+    import sys
+    import time
+    s = synth(300, seed=5, m=60)
+    out_bin, fasta, L = _write_intermediates(tmp_path, s, ["r%d" % i for i in range(300)])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "fedrann_amd", "-o", str(tmp_path / "o"), "--devices", "0,99", "--dist-backend",
+                        "gloo", "-n", "128", "--nndescent-n-neighbors", "20", "--kmer-searcher-output", out_bin,
+                        "--kmer-library", fasta], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "rank worker(s) failed" in (r.stderr + r.stdout)
+    assert time.time() - t0 < 120
+
+
 def test_cli_fastq_headers_follow_the_fasta_id_rule(tmp_path, oracle):
     """The reference converts FASTQ to FASTA (seqkit fq2fa, count_kmers.py:76-79) before kmer_searcher sees
     it, so a read's name is its header up to the first space OR TAB: ONT / PacBio style descriptions and

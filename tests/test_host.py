@@ -300,3 +300,66 @@ def test_cli_flags_match_reference_defaults():
     assert (a.threads, a.chunk_size, a.embedding_dimension) == (1, 1000, 500)
     assert (a.nndescent_n_trees, a.nndescent_n_neighbors, a.seed) == (300, 50, 356115)
     assert not a.save_feature_matrix and not a.keep_intermediates and not a.mprof
+
+
+def test_native_overlaps_writer_quotes_names_and_blanks_nan_like_pandas(tmp_path):
+    """csv.QUOTE_MINIMAL as DataFrame.to_csv applies it: a name with the separator, a double quote or a line feed
+    is quoted (quotes doubled), a carriage return alone is not; a NaN distance is an empty field."""
+    from fedrann_amd.__main__ import write_overlaps
+    names = ['a"b', "c\rd", "e\nf", "g\th", " lead", "x", "q,r", "s't", '""', "plain"]
+    n, k = len(names), 4
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, n, size=(n, k)).astype(np.int32)
+    dist = rng.random((n, k)).astype(np.float32)
+    dist[1, 2] = np.nan
+    dist[4, 0] = np.nan
+    strands = [i % 2 for i in range(n)]
+    df = get_output_dataframe(idx, dist, names, strands)
+    buf = io.StringIO()
+    df.to_csv(buf, sep="\t", index=False)
+    p = tmp_path / "o.tsv"
+    assert write_overlaps(str(p), idx, dist, names, strands) == df.shape[0]
+    assert p.read_bytes() == buf.getvalue().encode()
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_native_output_bin_loader_record_range(tmp_path, oracle, threads):
+    """fdr_kmer_output_load_range: one rank's block of rows (records [lo, hi)) equals the slice of the whole
+    matrix, the names are those of all records, empty and out-of-range blocks are handled."""
+    from fedrann_amd import _lib
+    from fedrann_amd.__main__ import doubled_names
+    rng = np.random.default_rng(11)
+    L, R = 5000, 700
+    path = tmp_path / "output.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sB3sQ", b"KMER", 1, b"\0\0\0", R))
+        for r in range(R):
+            name = b"read_%d" % r if r % 50 else b""
+            cnt = 0 if r % 97 == 0 else int(rng.integers(1, 300))
+            ids = rng.choice(2 * L, size=cnt, replace=False).astype("<u8")
+            f.write(struct.pack("<H", len(name)) + name + struct.pack("<I", cnt) + ids.tobytes())
+    ip, ix, noff, nbuf = _lib.kmer_output_load(str(path), 2 * L, threads)
+    for lo, hi in ((0, R), (0, 1), (100, 356), (699, 700), (350, 350), (650, 9999)):
+        total, bip, bix, boff, bbuf = _lib.kmer_output_load_range(str(path), 2 * L, lo, hi, n_threads=threads)
+        hi = min(hi, R)
+        assert total == R
+        assert np.array_equal(bip, ip[2 * lo:2 * hi + 1] - ip[2 * lo])
+        assert np.array_equal(bix, ix[ip[2 * lo]:ip[2 * hi]])
+        assert np.array_equal(boff, noff) and np.array_equal(bbuf, nbuf)
+    total, bip, bix, boff, bbuf = _lib.kmer_output_load_range(str(path), 2 * L, 10, 20, with_names=False)
+    assert boff is None and bbuf is None and bip.size == 21
+    # the writer's view of the names: every record twice
+    off2, buf2 = doubled_names(noff, nbuf)
+    want = [bytes(nbuf[noff[r]:noff[r + 1]]) for r in range(R) for _ in (0, 1)]
+    assert [bytes(buf2[off2[i]:off2[i + 1]]) for i in range(2 * R)] == want
+
+
+def test_doubled_names_follow_the_reference_rule_for_invalid_utf8():
+    from fedrann_amd import _lib
+    from fedrann_amd.__main__ import doubled_names
+    ids = [b"ok", b"caf\xc3\xa9", b"bad\xff\xfeid", b""]
+    off = np.zeros(len(ids) + 1, dtype=np.int64)
+    np.cumsum([len(b) for b in ids], out=off[1:])
+    off2, buf2 = doubled_names(off, np.frombuffer(b"".join(ids), dtype=np.uint8))
+    got = [bytes(buf2[off2[i]:off2[i + 1]]) for i in range(2 * len(ids))]
+    assert got == [b"ok", b"ok", "café".encode(), "café".encode(), b"bad__id", b"bad__id", b"", b""]
