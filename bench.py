@@ -359,13 +359,19 @@ def main():
         # gfx950 guide prescribes + WRITE_SIZE); only valid for the workload the profile was collected on
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r2_summary.json")) as f:
-                prof = json.load(f)
-            if prof.get("bench_args") == {"reads": R, "dim": d, "knn": k, "gpus": world, "doubling": args.doubling}:
-                kname = "knn_prefilter_kernel" if used_prefilter else "knn_tile_kernel"
-                traffic = prof["pmc_per_launch_avg"][kname]["hbm_bytes_per_launch"]
-                traffic_src = ("profiles/r2_summary.json (rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + "
-                               "WRITE_SIZE, bytes per launch, same workload)")
+            import glob
+            import re
+            summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")),
+                               key=lambda f: int(re.search(r"r(\d+)", os.path.basename(f)).group(1)), reverse=True)
+            for path in summaries:  # the newest round's profile of THIS workload
+                with open(path) as f:
+                    prof = json.load(f)
+                if prof.get("bench_args") == {"reads": R, "dim": d, "knn": k, "gpus": world, "doubling": args.doubling}:
+                    kname = "knn_prefilter_kernel" if used_prefilter else "knn_tile_kernel"
+                    traffic = prof["pmc_per_launch_avg"][kname]["hbm_bytes_per_launch"]
+                    traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, bytes "
+                                   "per launch, same workload)" % os.path.basename(path))
+                    break
         except Exception:
             traffic = None
         result = {

@@ -21,10 +21,10 @@ SYMBOLS = (
     "fdr_overlaps_write", "fdr_last_prefilter_launches", "fdr_knn_classes_dev", "fdr_knn_unique_dev",
     "fdr_knn_expand_dev", "fdr_kmer_output_scan_range", "fdr_kmer_output_load_range",
 )
-FDR_MAX_K = 64
+FDR_MAX_K = 128
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
            "knn_dedup", "kmer_search", "kmer_compact")
-FDR_MAX_DIM = 512
+FDR_MAX_DIM = 2048
 
 
 class FedrannHipError(RuntimeError):

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restr
 #include "knn_prefilter.inc"  // P1 / P2: fp16 MFMA candidate pass, merges, certificate + re-rank, range pass
 #include "knn_order.inc"      // P1: scan order by chunk mask (sort keys, ordered fp16 copy)
 #include "dedup_classes.inc"  // duplicate-row classes: hash, tables, gathers, expansion
+#include "knn_generic.inc"    // d > 512 or k > 64: every pair on the vector ALU
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -470,8 +471,12 @@ static int launch_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *d_indptr,
         FDR_LAUNCH_EMBED(128);
     else if (dp == 256)
         FDR_LAUNCH_EMBED(256);
-    else
+    else if (dp == 512)
         FDR_LAUNCH_EMBED(512);
+    else if (dp == 1024)
+        FDR_LAUNCH_EMBED(1024);
+    else
+        FDR_LAUNCH_EMBED(2048);
 #undef FDR_LAUNCH_EMBED
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_EMBED, st);
@@ -483,7 +488,7 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
     if (dp < 0) return fail(FDR_E_ARG, "normalize: dimension %d unsupported (1..%d)", d, FDR_MAX_DIM);
     if (n_rows < 0) return fail(FDR_E_ARG, "normalize: n_rows < 0");
     if (n_rows == 0) return FDR_OK;
-    const int rb = dp == 128 ? 64 : (dp == 256 ? 32 : 16);
+    const int rb = dp == 128 ? 64 : dp == 256 ? 32 : dp == 512 ? 16 : dp == 1024 ? 8 : 4;
     const long long grid = (n_rows + rb - 1) / rb;
     if (grid > 0x7fffffffll) return fail(FDR_E_ARG, "normalize: too many rows");
     int trc = timing_begin(ctx, FDR_KERNEL_NORMALIZE, st);
@@ -494,14 +499,21 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
     else if (dp == 256)
         hipLaunchKernelGGL((normalize_rows_kernel<256, 32>), dim3((unsigned)grid), dim3(64), 0, st,
                            d_E, (long long)n_rows, d, d_Ehat, d_zero);
-    else
+    else if (dp == 512)
         hipLaunchKernelGGL((normalize_rows_kernel<512, 16>), dim3((unsigned)grid), dim3(64), 0, st,
+                           d_E, (long long)n_rows, d, d_Ehat, d_zero);
+    else if (dp == 1024)
+        hipLaunchKernelGGL((normalize_rows_kernel<1024, 8>), dim3((unsigned)grid), dim3(64), 0, st,
+                           d_E, (long long)n_rows, d, d_Ehat, d_zero);
+    else
+        hipLaunchKernelGGL((normalize_rows_kernel<2048, 4>), dim3((unsigned)grid), dim3(64), 0, st,
                            d_E, (long long)n_rows, d, d_Ehat, d_zero);
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_NORMALIZE, st);
 }
 
 static size_t knn_workspace_bytes_impl(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k);
+static bool knn_generic_wanted(int dp, int k) { return dp > FDR_FAST_MAX_DIM || k > FDR_FAST_MAX_K; }
 
 // ---- prefilter mode: workspace layout -------------------------------------------------------
 // mode: FDR_MODE_AUTO uses the fp16 prefilter whenever it applies (d <= 128, k + 8 <= 64) and the
@@ -509,8 +521,8 @@ static size_t knn_workspace_bytes_impl(const fdr_ctx *ctx, int64_t nq, int64_t n
 static bool knn_prefilter_wanted(const fdr_ctx *ctx, int dp, int64_t nt, int k) {
     const int mode = ctx->knn_mode;
     if (mode == FDR_MODE_EXACT) return false;
-    const int kp = (k + prefilter_extra() + 1) & ~1;
-    if (!(kp <= FDR_MAX_K && nt >= kp)) return false;
+    const int kp = (k + prefilter_extra(k) + 1) & ~1;
+    if (!(kp <= FDR_FAST_MAX_K && nt >= kp)) return false;
     if (nt > (int64_t)FDR_MAX_SEG << FDR_PREFILTER_MAX_IB) return false;  // segments too long for the keys
     return mode == FDR_MODE_PREFILTER || nt >= 8192;
 }
@@ -529,7 +541,7 @@ static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int d, int k) {
     PrefilterLayout L;
-    L.kp = (k + prefilter_extra() + 1) & ~1;
+    L.kp = (k + prefilter_extra(k) + 1) & ~1;
     L.chunk = (int)std::min<int64_t>(nq, 16384);
     const size_t exact_all = knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
     const int dp = fdr_padded_dim(d);
@@ -583,6 +595,7 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
 FDR_EXPORT size_t fdr_knn_workspace_bytes(fdr_ctx *ctx, int64_t nq, int64_t nt, int32_t d,
                                           int32_t k) {
     if (!ctx || nq <= 0 || nt <= 0 || k <= 0 || k > FDR_MAX_K || fdr_padded_dim(d) < 0) return 0;
+    if (knn_generic_wanted(fdr_padded_dim(d), k)) return 256;  // (the generic kernel needs no scratch)
     return knn_workspace_bytes_impl(ctx, nq, nt, d, k);
 }
 
@@ -592,7 +605,8 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
                       hipStream_t st) {
     const int dp = fdr_padded_dim(d);
     if (dp < 0) return fail(FDR_E_ARG, "knn: dimension %d unsupported (1..%d)", d, FDR_MAX_DIM);
-    if (k < 1 || k > FDR_MAX_K) return fail(FDR_E_ARG, "knn: k=%d unsupported (1..%d)", k, FDR_MAX_K);
+    if (k < 1 || k > FDR_FAST_MAX_K || dp > FDR_FAST_MAX_DIM)
+        return fail(FDR_E_ARG, "knn: k=%d, d=%d outside the MFMA kernels' shapes", k, d);
     if (nq < 0 || nt < k) return fail(FDR_E_ARG, "knn: need n_targets (%lld) >= k (%d)", (long long)nt, k);
     if (nt + t_base > 0x7fffffffll || nq > 0x7fffffffll)
         return fail(FDR_E_ARG, "knn: row numbers exceed int32");
@@ -765,6 +779,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     do {                                                                                                \
         for (long long base_ = it_lo; base_ < it_hi; base_ += per_launch, ++li) { /* (one queue: every launch its own timed span) */ \
             hipStream_t ls_ = qs[li % nqueues];                                                         \
+            if (lds > 32768) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             if (nqueues == 1 && (trc = timing_begin(ctx, FDR_KERNEL_KNN_PREFILTER, ls_))) return trc;   \
             hipLaunchKernelGGL(KERNEL_, dim3((unsigned)std::min(per_launch, it_hi - base_)), dim3(THREADS_), lds, \
                                ls_, p1_q, (int)nq, p1_t, (int)nt, (int)t_base, p.segs, kp, p.nq_pad, d_partial, \
@@ -772,7 +787,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             if (nqueues == 1 && (trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, ls_))) return trc;     \
         }                                                                                               \
     } while (0)
-#define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_) /* (the ring is at most 32 KB: no dynamic-LDS attribute) */ \
+#define FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, LH_) \
     FDR_LAUNCH_PRE3((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>), 64 * NW_)
 #define FDR_LAUNCH_PRE(DP_, NQ_, NW_, WPS_, U_)                                                         \
     do {                                                                                                \
@@ -785,6 +800,8 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             if (sh.nw == 8) FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512);
             else FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
         } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
+        else if (dp == 256 && sh.tps == 8) FDR_LAUNCH_PRE(256, 1, 4, 2, 4);
+        else if (dp == 512 && sh.tps == 8) FDR_LAUNCH_PRE(512, 1, 4, 2, 4);
         else if (dp == 256 && sh.wps == 2 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 2, 2);
         else if (dp == 256 && sh.wps == 2) FDR_LAUNCH_PRE(256, 1, 4, 2, 2);
         else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
@@ -858,7 +875,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                                dp, d_hqc, d_thetac, d_cnt);
             HIP_TRY(hipGetLastError());
             const KnnPlan rp = knn_plan(ctx->num_cus, c, nt, d, 1, range_shape(dp));  // (k = 1: ring-only LDS)
-            const size_t rlds = (size_t)2 * 32 * 256;
+            const size_t rlds = (size_t)RANGE_STAGES * 32 * 256;
 #define FDR_LAUNCH_RANGE(DP_, WPS_)                                                                     \
     hipLaunchKernelGGL((knn_range_kernel<DP_, 4, WPS_>), dim3((unsigned)rp.nqb, (unsigned)rp.nseg),        \
                        dim3(256), rlds, st, (const _Float16 *)d_hqc, (const float *)d_thetac, c,          \
@@ -908,7 +925,7 @@ static int launch_knn_mode(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_q
                            const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int d,
                            int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes, hipStream_t st) {
     const int dp = fdr_padded_dim(d);
-    if (dp > 0 && k >= 1 && k <= FDR_MAX_K && nq > 0 && nt >= k && knn_prefilter_wanted(ctx, dp, nt, k) &&
+    if (dp > 0 && k >= 1 && k <= FDR_FAST_MAX_K && nq > 0 && nt >= k && knn_prefilter_wanted(ctx, dp, nt, k) &&
         d_Qhat && d_qzero && d_That && d_tzero && d_idx && d_dist && d_ws)
         return launch_knn_prefilter(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx,
                                     d_dist, d_ws, ws_bytes, st);
@@ -976,11 +993,28 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
                       const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base, int d,
                       int k, int32_t *d_idx, float *d_dist, void *d_ws, size_t ws_bytes, hipStream_t st) {
     const int dp = fdr_padded_dim(d);
+    if (dp > 0 && k >= 1 && k <= FDR_MAX_K && knn_generic_wanted(dp, k)) {  // beyond the MFMA kernels' shapes
+        if (nq < 0 || nt < k) return fail(FDR_E_ARG, "knn: need n_targets (%lld) >= k (%d)", (long long)nt, k);
+        if (nt + t_base > 0x7fffffffll || nq > 0x7fffffffll) return fail(FDR_E_ARG, "knn: row numbers exceed int32");
+        if (nq == 0) return FDR_OK;
+        if (!d_Qhat || !d_qzero || !d_That || !d_tzero || !d_idx || !d_dist) return fail(FDR_E_ARG, "knn: null device pointer");
+        ctx->last_unique_targets = (int)nt;
+        ctx->last_unique_queries = (int)nq;
+        ctx->last_flagged = 0;
+        ctx->last_pass_launches = ctx->last_pass_queues = 0;
+        int trc = timing_begin(ctx, FDR_KERNEL_KNN_TILE, st);
+        if (trc) return trc;
+        hipLaunchKernelGGL(knn_generic_kernel, dim3((unsigned)((nq + GEN_QPB - 1) / GEN_QPB)), dim3(256),
+                           (size_t)GEN_QPB * dp * 4, st, d_Qhat, d_qzero, (int)nq, d_That, d_tzero, (int)nt, (int)t_base, dp, k,
+                           d_idx, d_dist);
+        HIP_TRY(hipGetLastError());
+        return timing_end(ctx, FDR_KERNEL_KNN_TILE, st);
+    }
     // the queries must be a block of the target rows (they are in every caller of this library)
     const bool q_in_t = d_Qhat && d_That && dp > 0 && d_Qhat >= d_That &&
                         d_Qhat + (size_t)nq * dp <= d_That + (size_t)nt * dp &&
                         ((d_Qhat - d_That) % dp) == 0;
-    if (!(dp > 0 && k >= 1 && k <= FDR_MAX_K && nq > 0 && nt >= k && q_in_t && knn_dedup_wanted(ctx, nq, nt) &&
+    if (!(dp > 0 && k >= 1 && k <= FDR_FAST_MAX_K && nq > 0 && nt >= k && q_in_t && knn_dedup_wanted(ctx, nq, nt) &&
           d_qzero && d_tzero && d_idx && d_dist && d_ws)) {
         ctx->last_unique_targets = (int)nt;
         ctx->last_unique_queries = (int)nq;
@@ -1118,6 +1152,7 @@ FDR_EXPORT int fdr_knn_classes_dev(fdr_ctx *ctx, const float *d_That, const uint
     if (dp < 0 || k < 1 || k > FDR_MAX_K || nt < k || nq_max <= 0 || nq_max > nt || !d_That || !d_tzero || !d_ws ||
         nt > 0x7fffffffll)
         return fail(FDR_E_ARG, "knn_classes: bad argument");
+    if (knn_generic_wanted(dp, k)) return FDR_OK;  // (no classes beyond the MFMA kernels' shapes: the callers use fdr_knn_dev)
     if (!knn_dedup_wanted(ctx, nq_max, nt)) return FDR_OK;  // (small sets: the callers use fdr_knn_dev)
     const DedupLayout L = dedup_layout(ctx, nq_max, nt, d, k);
     if (ws_bytes < L.total) return fail(FDR_E_ARG, "knn_classes: workspace %zu < required %zu bytes", ws_bytes, L.total);

@@ -43,8 +43,9 @@ extern "C" {
 #define FDR_E_STATE (-5)   /* call order (e.g. embed before a projection was loaded) */
 #define FDR_E_IO (-6)      /* a file could not be opened / mapped */
 
-#define FDR_MAX_K 64       /* neighbours per row (self included) supported by the top-k kernel */
-#define FDR_MAX_DIM 512    /* embedding dimension supported by the k-NN kernel (reference default: 500) */
+#define FDR_MAX_K 128      /* neighbours per row (self included); up to 64 on the MFMA kernels, beyond on a generic one */
+#define FDR_MAX_DIM 2048   /* embedding dimension; up to 512 (reference default: 500) on the MFMA kernels, beyond on a
+                              generic vector-ALU kernel (same results, far slower: DESIGN.md) */
 
 typedef struct fdr_ctx fdr_ctx;
 
@@ -55,7 +56,8 @@ const char *fdr_last_error(void);
 /* "name|gcnArch|CUs|HBM bytes" of the context's device, NUL-terminated into buf. */
 int fdr_device_info(fdr_ctx *ctx, char *buf, int buflen);
 /* Padded row length (floats) of the internal normalised-embedding layout for dimension d:
- * 128 for d <= 128, 256 for d <= 256, 512 for d <= 512; negative if d is unsupported. */
+ * 128 for d <= 128, 256 for d <= 256, 512 for d <= 512, 1024 for d <= 1024, 2048 for d <= 2048; negative if d is
+ * unsupported. */
 int fdr_padded_dim(int d);
 
 /* ---- projection (replaces handing `precompute_matrix` to get_feature_matrix,
@@ -96,7 +98,8 @@ int fdr_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr, const int32
  * ascending by (distance, index); self is a candidate like any other row.  Canonical arithmetic
  * (DESIGN.md "k-NN arithmetic"): rows are scaled by (float)(1/sqrt((double)chain(x,x))), the
  * similarity is the fp32 fma chain over components 0..d-1, dist = clamp(1 - c, 0, 1), two
- * all-zero rows are at distance 0.  Requires n >= k, 1 <= k <= FDR_MAX_K, d <= FDR_MAX_DIM. */
+ * all-zero rows are at distance 0.  Requires n >= k, 1 <= k <= FDR_MAX_K, d <= FDR_MAX_DIM (k > 64 or d > 512: the
+ * generic kernel, every pair on the vector ALU). */
 int fdr_knn(fdr_ctx *ctx, const float *E, int64_t n, int32_t d, int32_t k, int32_t *idx_out,
             float *dist_out);
 

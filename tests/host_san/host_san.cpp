@@ -113,7 +113,7 @@ static int cmd_tables(unsigned seed, long long F, int d) {
             bc[bc.size() / 2] = d;
             if (build_projection_tables(F, d, indptr.data(), bc.data(), vals.data(), U) == FDR_OK) return printf("FAIL column\n"), 1;
         }
-        if (build_projection_tables(F, 513, indptr.data(), cols.data(), vals.data(), U) == FDR_OK) return printf("FAIL dim\n"), 1;
+        if (build_projection_tables(F, FDR_MAX_DIM + 1, indptr.data(), cols.data(), vals.data(), U) == FDR_OK) return printf("FAIL dim\n"), 1;
     }
     // compaction of a random CSR (incl. empty rows, ids outside [0, F)) at 1 and 5 threads == a serial filter
     std::vector<uint32_t> bits(T.ftab.size());
@@ -183,8 +183,8 @@ static int cmd_plan() {
                     for (int64_t nq : {nt, (nt + 7) / 8, (int64_t)1}) {
                         bad += check_plan(cus, nq, nt, d, k, -1);  // exact shapes
                         ++n;
-                        const int kp = (k + prefilter_extra() + 1) & ~1;
-                        if (kp <= FDR_MAX_K && nt >= kp) {
+                        const int kp = (k + prefilter_extra(k) + 1) & ~1;
+                        if (kp <= FDR_FAST_MAX_K && nt >= kp) {
                             bad += check_plan(cus, nq, nt, d, kp, prefilter_shape(dp, kp, nq, cus));
                             bad += check_plan(cus, nq, nt, d, 1, range_shape(dp));
                             n += 2;

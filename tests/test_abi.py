@@ -33,7 +33,8 @@ def test_padded_dim_needs_no_gpu(lib):
     assert lib.fdr_padded_dim(1) == 128 and lib.fdr_padded_dim(128) == 128
     assert lib.fdr_padded_dim(129) == 256 and lib.fdr_padded_dim(256) == 256
     assert lib.fdr_padded_dim(257) == 512 and lib.fdr_padded_dim(500) == 512
-    assert lib.fdr_padded_dim(513) < 0 and lib.fdr_padded_dim(0) < 0
+    assert lib.fdr_padded_dim(513) == 1024 and lib.fdr_padded_dim(1025) == 2048  # (the generic kernel's sizes)
+    assert lib.fdr_padded_dim(2049) < 0 and lib.fdr_padded_dim(0) < 0
 
 
 def test_no_gpu_fails_loudly(lib):

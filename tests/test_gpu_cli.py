@@ -34,7 +34,7 @@ def _write_intermediates(tmp_path, s, names):
     return str(out_bin), str(fasta), L
 
 
-@pytest.mark.parametrize("d,k", [(128, 20), (500, 50)])
+@pytest.mark.parametrize("d,k", [(128, 20), (500, 50), (1000, 100)])  # (the last: beyond the MFMA kernels' shapes)
 def test_cli_from_kmer_searcher_output(tmp_path, oracle, d, k):
     s = synth(900, seed=5, m=80)  # one row per record; the CLI doubles them (fwd + mirrored strand)
     names = ["read_%d/ccs" % i for i in range(900)]
@@ -256,7 +256,7 @@ def test_cli_fastq_headers_follow_the_fasta_id_rule(tmp_path, oracle):
 
 
 def test_cli_refuses_unsupported_sizes_before_any_work(tmp_path):
-    for extra in (["-n", "1000"], ["--nndescent-n-neighbors", "100"]):
+    for extra in (["-n", "3000"], ["--nndescent-n-neighbors", "200"]):
         with pytest.raises(SystemExit) as e:
             cli.main(["-o", str(tmp_path / "o"), "--feature-matrix", "missing.npz", "--kmer-counts", "missing.npy"] + extra)
         assert "GPU k-NN kernels" in str(e.value)

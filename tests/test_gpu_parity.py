@@ -347,6 +347,40 @@ def test_device_api_query_subset_like_a_rank(ctx, oracle):
         _assert_knn_equal((idx.cpu().numpy(), dst.cpu().numpy()), (wi[lo:hi], wd[lo:hi]))
 
 
+# ---- beyond the MFMA kernels' shapes: d > 512 or k > 64 on the generic kernel ------------------------------
+@pytest.mark.parametrize("n,d,k", [(3000, 1000, 100), (2500, 600, 50), (4000, 128, 100), (700, 2048, 128),
+                                   (1500, 513, 65), (130, 700, 128)])
+def test_knn_generic_kernel_matches_oracle(ctx, oracle, n, d, k):
+    """The reference accepts any -n / --nndescent-n-neighbors (__main__.py:128-146): sizes outside the MFMA
+    kernels' shapes run on knn_generic_kernel with the same canonical arithmetic -- sparse rows with ties,
+    duplicates and all-zero rows, indices and distance bits against the oracle."""
+    rng = np.random.default_rng(n + d + k)
+    E = np.zeros((n, d), np.float32)
+    nnz = 6
+    cols = rng.integers(0, d, size=(n, nnz))
+    vals = (rng.integers(1, 5, size=(n, nnz)) * 0.37 * rng.choice([-1.0, 1.0], size=(n, nnz))).astype(np.float32)
+    np.put_along_axis(E, cols, vals, axis=1)
+    E[::17] = 0.0               # all-zero rows
+    E[5::40] = E[3]             # exact duplicates (ties decided by the index)
+    E[7::50] = 2.5 * E[4]       # scaled copies
+    got = ctx.knn(E, k)
+    _assert_knn_equal(got, oracle.knn(E, k))
+
+
+def test_embed_knn_at_dimension_1000(ctx, oracle):
+    """-n 1000: projection tables, embed (DP = 1024 accumulators), normalise and the generic k-NN, end to end
+    against the oracle."""
+    from fedrann_amd.precompute import build_precompute_matrix
+    from fedrann_amd.synth import synth
+    s = synth(1500, seed=31, m=120)
+    P = build_precompute_matrix(s["counts"], 1000)
+    ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], 1000)
+    idx, dist, E = ctx.embed_knn(s["indptr"], s["indices"], 100, return_embedding=True)
+    want_E = oracle.embed(s["indptr"], s["indices"], (P.indptr, P.indices, P.data), s["n_features"], 1000)
+    assert np.array_equal(E.view(np.uint32), want_E.view(np.uint32))
+    _assert_knn_equal((idx, dist), oracle.knn(want_E, 100))
+
+
 # ---- error behaviour -----------------------------------------------------------------------------
 def test_errors_are_raised_not_swallowed(ctx):
     E = np.zeros((10, 16), np.float32)
@@ -355,9 +389,9 @@ def test_errors_are_raised_not_swallowed(ctx):
     with pytest.raises(_lib.FedrannHipError):
         ctx.knn(E, 0)
     with pytest.raises(_lib.FedrannHipError):
-        ctx.knn(np.zeros((100, 600), np.float32), 5)  # d > FDR_MAX_DIM
+        ctx.knn(np.zeros((100, 2049), np.float32), 5)  # d > FDR_MAX_DIM
     with pytest.raises(_lib.FedrannHipError):
-        ctx.knn(np.zeros((100, 16), np.float32), 65)  # k > FDR_MAX_K
+        ctx.knn(np.zeros((200, 16), np.float32), 129)  # k > FDR_MAX_K
     fresh = _lib.Context(0)
     with pytest.raises(_lib.FedrannHipError):
         fresh.embed(np.array([0, 1], np.int64), np.array([0], np.int32))  # no projection loaded
