@@ -273,7 +273,7 @@ def main():
 
     elapsed, kernel_ms, kernel_cnt, out = timed_run(args.steps, args.warmup)
     uncertified = ctx.last_uncertified()
-    uniq_t, uniq_q = ctx.last_unique()  # rows actually searched (duplicate-row classes, DESIGN.md 6c)
+    uniq_t, uniq_q = ctx.last_unique()  # rows actually searched (duplicate-row classes, DESIGN.md section 5 C)
     pass_launches, pass_queues = ctx.last_prefilter_launches()
     used_prefilter = kernel_cnt["knn_prefilter"] > 0
 

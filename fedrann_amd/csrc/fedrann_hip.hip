@@ -35,7 +35,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#include "host_common.inc"  // error plumbing, FDR_EXPORT, dev_env (plain C++: shared with the sanitizer build)
+#include "host_common.inc"  // error plumbing, FDR_EXPORT, the development knobs (plain C++: shared with the sanitizer build)
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -570,7 +570,7 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.off_thetac = o;   o += align256((size_t)L.rchunk * 4);
     L.off_cnt = o;      o += align256((size_t)L.rchunk * 4);
     L.off_rcand = o;    o += align256((size_t)L.rchunk * RANGE_CAP * 4);
-    L.ordered = pp.cohort > 0 || dev_env_int("FDR_KNN_ORDERED", 0) != 0;  // (the sizes at which the pass runs in synchronised rounds)
+    L.ordered = pp.cohort > 0 || dev_knobs().ordered != 0;  // (the sizes at which the pass runs in synchronised rounds)
     L.off_okeys = L.off_okeys_s = L.off_ovals = L.off_perm_t = L.off_perm_q = L.off_ho_t = L.off_ho_q = 0;
     L.off_otmp = L.otmp_bytes = 0;
     if (L.ordered) {
@@ -626,7 +626,7 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
     const size_t lds = knn_lds_bytes(sh, k);
     if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn: k=%d, d=%d needs %zu B of LDS (> 160 KiB)", k, d, lds);
     dim3 grid((unsigned)p.nqb, (unsigned)p.nseg);
-    const int dbg = dev_env_int("FDR_KNN_DEBUG", 0);  // development knob (-DFDR_DEV builds only)
+    const int dbg = dev_knobs().debug;  // (development builds only; 0 in the release library)
     (void)dbg;
     int trc = timing_begin(ctx, FDR_KERNEL_KNN_TILE, st);
     if (trc) return trc;
@@ -740,7 +740,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     const int ib = prefilter_index_bits(max_seg);
     if (ib > FDR_PREFILTER_MAX_IB) return fail(FDR_E_ARG, "knn prefilter: segment of %d rows", max_seg);
     if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
-    const int pdbg = dev_env_int("FDR_KNN_DEBUG", 0);
+    const int pdbg = dev_knobs().debug;
     (void)pdbg;
     // the nqb * nseg work items in launches of p.cohort workgroups (0: one launch): see knn_plan_compute
     const long long n_items = (long long)p.nqb * p.nseg;

@@ -18,10 +18,10 @@
  *     call only.  "host" functions take host pointers and synchronise before returning; "_dev"
  *     functions take device pointers (hipMalloc'd or a torch tensor's data_ptr()) plus a
  *     hipStream_t passed as void* and enqueue work on that stream.  fdr_embed_dev and fdr_normalize_dev
- *     return without synchronising; fdr_knn_dev synchronises the stream up to four times (it sizes its
- *     follow-up passes from counters it reads back: duplicate-row probe, unique-row counts, uncertified /
- *     all-zero / plateau queries, overflowing ranges), so work the caller wants to overlap with it
- *     belongs on another stream.
+ *     return without synchronising; fdr_knn_dev synchronises the stream twice on the common path (it sizes its
+ *     follow-up passes from counters it reads back: unique-row counts; uncertified / all-zero / plateau queries; below
+ *     2^18 targets a duplicate-row probe, and once more when a plateau's range overflows), so work the caller wants
+ *     to overlap with it belongs on another stream.
  *   - one context = one GPU; one context per process is the intended use (one process per GPU).
  *     A context is not re-entrant: one call in flight at a time.
  *   - all arrays are C-contiguous with exactly the element types written here.
@@ -96,7 +96,7 @@ int fdr_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr, const int32
  *      index_n_neighbors=k, ...).neighbor_graph, nearest_neighbors.py:39-55) ---------------
  * E float32 [n, d] (not normalised).  idx_out int32 [n,k], dist_out float32 [n,k], each row
  * ascending by (distance, index); self is a candidate like any other row.  Canonical arithmetic
- * (DESIGN.md "k-NN arithmetic"): rows are scaled by (float)(1/sqrt((double)chain(x,x))), the
+ * (DESIGN.md section 4): rows are scaled by (float)(1/sqrt((double)chain(x,x))), the
  * similarity is the fp32 fma chain over components 0..d-1, dist = clamp(1 - c, 0, 1), two
  * all-zero rows are at distance 0.  Requires n >= k, 1 <= k <= FDR_MAX_K, d <= FDR_MAX_DIM (k > 64 or d > 512: the
  * generic kernel, every pair on the vector ALU). */
@@ -168,8 +168,8 @@ int fdr_knn_expand_dev(fdr_ctx *ctx, int64_t q0, int64_t nq, int64_t t_base, con
 int fdr_timing(fdr_ctx *ctx, int enable);
 int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out);
 /* ---- k-NN mode ---------------------------------------------------------------------------------
- * Both modes return the SAME canonical result (DESIGN.md section 6b).  EXACT: every pair through the
- * fp32 MFMA kernel.  PREFILTER (k <= 56): an fp16 MFMA pass proposes k + 8 candidates per
+ * Both modes return the SAME canonical result (DESIGN.md section 5).  EXACT: every pair through the
+ * fp32 MFMA kernel.  PREFILTER (k <= 56): an fp16 MFMA pass proposes k + 12 (or k + 8) candidates per
  * query; a certificate proves they contain the exact top-k and their distances are recomputed with
  * the canonical fp32 chain; queries that cannot be certified are searched by the exact kernel.  The
  * prefilter mode reads one 4-byte counter back per call (a stream synchronisation).  AUTO (default):
@@ -180,7 +180,7 @@ int fdr_timing_read(fdr_ctx *ctx, int which, int *count_out, float *total_ms_out
 #define FDR_MODE_EXACT 1
 #define FDR_MODE_PREFILTER 2
 int fdr_set_knn_mode(fdr_ctx *ctx, int mode);
-/* Duplicate-row classes (DESIGN.md section 6c): bitwise-identical rows are searched once and the result
+/* Duplicate-row classes (DESIGN.md section 5 C): bitwise-identical rows are searched once and the result
  * expanded -- the same canonical result either way.  AUTO (default): from 8192 targets, when at least 5 % of
  * the rows repeat.  OFF: never.  ON: at every size (same 5 % test).  FORCE: always expand, even without
  * duplicates (the parity tests' "+classes" variants). */
