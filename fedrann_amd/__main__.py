@@ -446,9 +446,9 @@ def _gpu_kmer_search(reads_path, fwd_library, k, temp_dir):
             copyfileobj(src, dst, 1 << 24)
         reads_path = plain
     out_dir = join(temp_dir, "kmer_searcher")
-    ids, indptr, indices, n_lib = kmer_searcher([fwd_library, rev_path], reads_path, out_dir, k,
-                                                fastq_ids_as_fasta=True)  # (the reference runs seqkit fq2fa first)
-    logger.debug("k-mer search: %d reads, %d library k-mers, %d hits", len(ids), n_lib, indices.size)
+    n_reads, _, nnz, n_lib = kmer_searcher([fwd_library, rev_path], reads_path, out_dir, k, fastq_ids_as_fasta=True,
+                                           collect=False)  # (the reference runs seqkit fq2fa first; reads streamed)
+    logger.debug("k-mer search: %d reads, %d library k-mers, %d hits", n_reads, n_lib, nnz)
     return join(out_dir, "output.bin")
 
 

@@ -20,6 +20,7 @@ SYMBOLS = (
     "fdr_kmer_count_fetch", "fdr_set_kmer_count_block", "fdr_last_kmer_count_blocks", "fdr_csr_compact", "fdr_host_register", "fdr_host_unregister",
     "fdr_overlaps_write", "fdr_last_prefilter_launches", "fdr_knn_classes_dev", "fdr_knn_unique_dev",
     "fdr_knn_expand_dev", "fdr_kmer_output_scan_range", "fdr_kmer_output_load_range",
+    "fdr_kmer_count_begin", "fdr_kmer_count_add", "fdr_kmer_count_finish",
 )
 FDR_MAX_K = 128
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
@@ -102,6 +103,9 @@ def load_library():
     L.fdr_kmer_search_indices.argtypes = [vp, vp]
     L.fdr_kmer_count.argtypes = [vp, vp, vp, i64, i32, i64, p64]
     L.fdr_kmer_count_fetch.argtypes = [vp, vp, vp]
+    L.fdr_kmer_count_begin.argtypes = [vp, i32]
+    L.fdr_kmer_count_add.argtypes = [vp, vp, vp, i64]
+    L.fdr_kmer_count_finish.argtypes = [vp, i64, p64]
     L.fdr_set_kmer_count_block.argtypes = [vp, ctypes.c_int64]
     L.fdr_last_kmer_count_blocks.argtypes = [vp]
     L.fdr_timing.argtypes = [vp, ctypes.c_int]
@@ -293,6 +297,26 @@ class Context:
         n = ctypes.c_int64()
         self._check(self._L.fdr_kmer_count(self._h, seqs.ctypes.data, seq_off.ctypes.data, seq_off.size - 1, int(k),
                                            int(min_count), ctypes.byref(n)), "fdr_kmer_count")
+        codes = np.empty(n.value, dtype=np.uint64)
+        counts = np.empty(n.value, dtype=np.uint64)
+        self._check(self._L.fdr_kmer_count_fetch(self._h, codes.ctypes.data, counts.ctypes.data), "fdr_kmer_count_fetch")
+        return codes, counts
+
+    def kmer_count_begin(self, k):
+        """Incremental counting for a streaming reader: begin, add whole reads piece by piece, finish."""
+        self._check(self._L.fdr_kmer_count_begin(self._h, int(k)), "fdr_kmer_count_begin")
+
+    def kmer_count_add(self, seqs, seq_off):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        self._check(self._L.fdr_kmer_count_add(self._h, seqs.ctypes.data, seq_off.ctypes.data, seq_off.size - 1),
+                    "fdr_kmer_count_add")
+
+    def kmer_count_finish(self, min_count=1):
+        """(codes uint64 ascending, counts uint64) of the canonical k-mers with >= min_count occurrences in all the
+        reads added since kmer_count_begin."""
+        n = ctypes.c_int64()
+        self._check(self._L.fdr_kmer_count_finish(self._h, int(min_count), ctypes.byref(n)), "fdr_kmer_count_finish")
         codes = np.empty(n.value, dtype=np.uint64)
         counts = np.empty(n.value, dtype=np.uint64)
         self._check(self._L.fdr_kmer_count_fetch(self._h, codes.ctypes.data, counts.ctypes.data), "fdr_kmer_count_fetch")

@@ -21,7 +21,7 @@ from os.path import join
 import numpy as np
 
 from . import _lib, global_variables
-from .kmer_search import kmer_searcher, read_sequences
+from .kmer_search import iter_sequence_blocks, kmer_searcher
 
 _BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
 
@@ -75,8 +75,13 @@ def run_kmer_searcher(input_path, k, sample_fraction, min_multiplicity=2, contex
         input_path = plain
     if not input_path.endswith((".fasta", ".fa", ".fastq", ".fq")):
         raise ValueError("Unsupported file format. Please provide a FASTA or FASTQ file.")  # count_kmers.py:72-75
-    ids, seqs, off = read_sequences(input_path, fastq_ids_as_fasta=True)  # (the reference runs seqkit fq2fa first)
-    codes, counts = count_canonical_kmers(seqs, off, k, min_multiplicity, context=context)
+    # the reads are streamed twice (counting, then the search): the host never holds the read set
+    # (fastq_ids_as_fasta: the reference runs seqkit fq2fa first)
+    ctx = context or _lib.default_context()
+    ctx.kmer_count_begin(int(k))
+    for _, seqs, off in iter_sequence_blocks(input_path, fastq_ids_as_fasta=True):
+        ctx.kmer_count_add(seqs, off)
+    codes, counts = ctx.kmer_count_finish(int(min_multiplicity))
     keep = sample_kmers(codes.size, sample_fraction, global_variables.seed)
     fwd = join(tmp, "fwd_kmer_library.fasta")
     write_kmer_library(fwd, codes[keep], counts[keep], k)
@@ -87,5 +92,6 @@ def run_kmer_searcher(input_path, k, sample_fraction, min_multiplicity=2, contex
         for line in f:
             g.write(line if line.startswith(b">") else line.rstrip(b"\n").translate(comp)[::-1] + b"\n")
     out_dir = join(tmp, "kmer_searcher")
-    ids2, _, _, _ = kmer_searcher([fwd, rev], input_path, out_dir, k, context=context, fastq_ids_as_fasta=True)
-    return join(out_dir, "output.bin"), kmer_count * 2, len(ids2)
+    n_reads, _, _, _ = kmer_searcher([fwd, rev], input_path, out_dir, k, context=context, fastq_ids_as_fasta=True,
+                                     collect=False)
+    return join(out_dir, "output.bin"), kmer_count * 2, n_reads

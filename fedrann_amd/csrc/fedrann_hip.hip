@@ -230,6 +230,8 @@ struct fdr_ctx {
     long long ks_nnz = 0, kc_n = 0;
     int64_t kc_block_chars = 0;  // fdr_set_kmer_count_block
     int kc_blocks = 0;           // blocks of the last fdr_kmer_count
+    int kc_k = 0, kc_acc = 0;    // incremental counting: k (0: not begun), which of the ping / pong tables is current
+    long long kc_na = 0;         // ... its entries
     // timing: when enabled, every launch of kernel kind i gets its own hipEvent pair on the launch
     // stream; fdr_timing_read() sums the elapsed times of all launches since the last read
     int knn_mode = FDR_MODE_AUTO;

@@ -68,29 +68,19 @@ def fasta_id(header):
     return header[:cut]
 
 
-def read_sequences(path, fastq_ids_as_fasta=False):
-    """FASTA / FASTQ -> (ids list of bytes, seqs uint8 [total], seq_off int64 [R+1]) exactly as
-    kmer_searcher.cpp:153-200 reads them: FASTQ iff the first line starts with '@'.
-    fastq_ids_as_fasta: the PIPELINE never shows kmer_searcher a FASTQ file -- count_kmers.py:76-79 converts
-    it with `seqkit fq2fa` first, so a read's name is its header up to the first space or tab (the FASTA
-    rule) there, and a record with an empty name is dropped; the stand-alone tool keeps the whole line.  FASTA: id = header up
-    to the first space or tab; the sequence is every following line with only the '\\n' removed (a '\\r'
-    stays and is an invalid character); empty lines are skipped; a record whose id is empty, and anything
-    before the first header, is dropped.  FASTQ: id = the whole header line after '@', sequence = the
-    next line, then two lines are skipped."""
-    with open(path, "rb") as f:
-        raw = f.read()
+def _parse_records(raw, is_fastq, fastq_ids_as_fasta):
+    """Whole records in `raw` (bytes) -> (ids, seqs uint8, seq_off int64 [R+1]); see read_sequences."""
     data = np.frombuffer(raw, dtype=np.uint8)
     if data.size == 0:
         return [], np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64)
     nl = np.flatnonzero(data == 10)
     starts = np.concatenate(([0], nl + 1))
     ends = np.concatenate((nl, [data.size]))  # (exclusive, without the '\n')
-    if starts[-1] == data.size:               # the file ends with '\n': no further line
+    if starts[-1] == data.size:               # the piece ends with '\n': no further line
         starts, ends = starts[:-1], ends[:-1]
     lens = ends - starts
     first = data[np.minimum(starts, data.size - 1)]
-    if lens[0] > 0 and first[0] == ord("@"):  # ---- FASTQ ----
+    if is_fastq:
         ids, pieces, i, n = [], [], 0, starts.size
         while i < n:
             if lens[i] > 0 and first[i] == ord("@"):
@@ -128,6 +118,79 @@ def read_sequences(path, fastq_ids_as_fasta=False):
     off = np.zeros(seq_len.size + 1, dtype=np.int64)
     np.cumsum(seq_len, out=off[1:])
     return [x for x, ok in zip(ids, has_id) if ok], seqs, off
+
+
+def _complete_prefix(raw, is_fastq, eof):
+    """Bytes of `raw` that hold whole records only (what follows waits for the next piece of the file).  FASTA: up
+    to the last line that starts with '>'.  FASTQ: the reader's own walk over the lines -- a non-empty line starting
+    with '@' opens a record of four lines, any other line is skipped alone -- stopped at the first record whose four
+    lines are not all there yet."""
+    if eof:
+        return len(raw)
+    if not is_fastq:
+        p = raw.rfind(b"\n>")
+        return p + 1 if p >= 0 else 0
+    data = np.frombuffer(raw, dtype=np.uint8)
+    nl = np.flatnonzero(data == 10)
+    if nl.size == 0:
+        return 0
+    starts = np.concatenate(([0], nl[:-1] + 1))  # the complete (terminated) lines
+    ends = nl
+    n, i = starts.size, 0
+    while i < n:
+        if ends[i] > starts[i] and data[starts[i]] == ord("@"):
+            if i + 3 >= n:
+                return int(starts[i])
+            i += 4
+        else:
+            i += 1
+    return int(nl[-1]) + 1 if i == n else int(starts[min(i, n - 1)])
+
+
+def iter_sequence_blocks(path, fastq_ids_as_fasta=False, chunk_bytes=1 << 28):
+    """The records of a FASTA / FASTQ file in file order, a piece of the file at a time: yields (ids, seqs uint8,
+    seq_off int64) for consecutive groups of whole records.  The reference streams its reads through pipes
+    (count_kmers.py:131-139, kmer_searcher.cpp:284-292); this keeps the host at about chunk_bytes + one record
+    whatever the size of the read set.  Same records, names and sequences as read_sequences."""
+    with open(path, "rb") as f:
+        carry = f.read(chunk_bytes)
+        if not carry:
+            return
+        # (FASTQ iff the first line is non-empty and starts with '@': kmer_searcher.cpp:160-163)
+        first_nl = carry.find(b"\n")
+        first_line = carry if first_nl < 0 else carry[:first_nl]
+        is_fastq = len(first_line) > 0 and first_line[:1] == b"@"
+        while True:
+            more = f.read(chunk_bytes)
+            eof = len(more) == 0
+            buf = carry + more if more else carry
+            cut = _complete_prefix(buf, is_fastq, eof)
+            if cut > 0:
+                ids, seqs, off = _parse_records(buf[:cut], is_fastq, fastq_ids_as_fasta)
+                if ids:
+                    yield ids, seqs, off
+            carry = buf[cut:]
+            if eof:
+                return
+
+
+def read_sequences(path, fastq_ids_as_fasta=False):
+    """FASTA / FASTQ -> (ids list of bytes, seqs uint8 [total], seq_off int64 [R+1]) exactly as
+    kmer_searcher.cpp:153-200 reads them: FASTQ iff the first line starts with '@'.
+    fastq_ids_as_fasta: the PIPELINE never shows kmer_searcher a FASTQ file -- count_kmers.py:76-79 converts
+    it with `seqkit fq2fa` first, so a read's name is its header up to the first space or tab (the FASTA
+    rule) there, and a record with an empty name is dropped; the stand-alone tool keeps the whole line.  FASTA: id = header up
+    to the first space or tab; the sequence is every following line with only the '\\n' removed (a '\\r'
+    stays and is an invalid character); empty lines are skipped; a record whose id is empty, and anything
+    before the first header, is dropped.  FASTQ: id = the whole header line after '@', sequence = the
+    next line, then two lines are skipped.  (Whole file in memory: the pipeline uses iter_sequence_blocks.)"""
+    with open(path, "rb") as f:
+        raw = f.read()
+    if not raw:
+        return [], np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64)
+    first_nl = raw.find(b"\n")
+    first_line = raw if first_nl < 0 else raw[:first_nl]
+    return _parse_records(raw, len(first_line) > 0 and first_line[:1] == b"@", fastq_ids_as_fasta)
 
 
 def search(seqs, seq_off, lib_codes, k, context=None, block_chars=1 << 31):
@@ -180,12 +243,30 @@ def write_kmer_frequency_bin(path, indices, n_lib):
     out.tofile(path)
 
 
-def kmer_searcher(kmer_lib, input_reads, output_dir, k, threads=None, context=None, fastq_ids_as_fasta=False):
+def _append_records(f, ids, indptr, indices):
+    """Records of output.bin (kmer_searcher.cpp:106-128) appended to the open file f."""
+    idx64 = np.asarray(indices).astype("<u8")
+    ptr = np.asarray(indptr).tolist()
+    for r, name in enumerate(ids):
+        if any(c < 32 or c > 126 for c in name):
+            raise ValueError("ID contains non-ASCII characters")
+        a, b = ptr[r], ptr[r + 1]
+        f.write(struct.pack("<H", len(name)))
+        f.write(name)
+        f.write(struct.pack("<I", b - a))
+        f.write(idx64[a:b].tobytes())
+
+
+def kmer_searcher(kmer_lib, input_reads, output_dir, k, threads=None, context=None, fastq_ids_as_fasta=False,
+                  collect=True, chunk_bytes=1 << 28):
     """Drop-in for the command line `kmer_searcher <kmer_lib> <input> <output_dir> <k> <threads>`
     (kmer_searcher.cpp:232-375).  `kmer_lib`: a path, a list of paths (read in order, like
     `cat fwd rev | grep -v '^>'`; '>' header tokens are not k long and drop out by themselves unless a
     count happens to have k digits -- so, as in the reference's pipeline, header lines are removed first).
-    Writes output_dir/output.bin and output_dir/kmer_frequency.bin; returns (ids, indptr, indices, n_lib).
+    Writes output_dir/output.bin and output_dir/kmer_frequency.bin.  The reads are STREAMED (iter_sequence_blocks):
+    a piece of the file is parsed, searched on the GPU and its records appended; the record count in the header is
+    patched at the end.  Returns (ids, indptr, indices, n_lib) -- with collect=False (the pipeline: nothing of the
+    read set is kept on the host) ids is the number of reads, indptr None and indices the number of hits.
     fastq_ids_as_fasta: see read_sequences (the pipeline's callers set it)."""
     paths = [kmer_lib] if isinstance(kmer_lib, (str, bytes, os.PathLike)) else list(kmer_lib)
     texts = []
@@ -194,9 +275,31 @@ def kmer_searcher(kmer_lib, input_reads, output_dir, k, threads=None, context=No
             t = f.read()
         texts.append(b"\n".join(l for l in t.split(b"\n") if not l.startswith(b">")) + b"\n")
     codes = load_kmer_library(texts, k)
-    ids, seqs, off = read_sequences(input_reads, fastq_ids_as_fasta=fastq_ids_as_fasta)
-    indptr, indices = search(seqs, off, codes, k, context=context)
     os.makedirs(output_dir, exist_ok=True)
-    write_output_bin(os.path.join(output_dir, "output.bin"), ids, indptr, indices)
-    write_kmer_frequency_bin(os.path.join(output_dir, "kmer_frequency.bin"), indices, codes.size)
-    return ids, indptr, indices, int(codes.size)
+    freq = np.zeros(int(codes.size), dtype=np.int64)
+    all_ids, ptr_parts, idx_parts, n_reads, nnz = [], [np.zeros(1, dtype=np.int64)], [], 0, 0
+    with open(os.path.join(output_dir, "output.bin"), "wb", buffering=1 << 24) as f:
+        f.write(struct.pack("<4sB3sQ", b"KMER", 1, b"\0\0\0", 0))
+        for ids, seqs, off in iter_sequence_blocks(input_reads, fastq_ids_as_fasta=fastq_ids_as_fasta,
+                                                   chunk_bytes=chunk_bytes):
+            indptr, indices = search(seqs, off, codes, k, context=context)
+            _append_records(f, ids, indptr, indices)
+            if indices.size:
+                freq += np.bincount(indices, minlength=freq.size)
+            if collect:
+                all_ids += ids
+                ptr_parts.append(indptr[1:] + nnz)
+                idx_parts.append(indices)
+            n_reads += len(ids)
+            nnz += int(indices.size)
+        f.seek(8)
+        f.write(struct.pack("<Q", n_reads))
+    nz = np.flatnonzero(freq)
+    out = np.empty((nz.size, 2), dtype="<u8")
+    out[:, 0] = nz
+    out[:, 1] = freq[nz]
+    out.tofile(os.path.join(output_dir, "kmer_frequency.bin"))
+    if not collect:
+        return n_reads, None, nnz, int(codes.size)
+    indices = np.concatenate(idx_parts) if idx_parts else np.empty(0, dtype=np.int32)
+    return all_ids, np.concatenate(ptr_parts), indices, int(codes.size)

@@ -231,6 +231,12 @@ int fdr_kmer_search_indices(fdr_ctx *ctx, int32_t *indices_out);
 int fdr_kmer_count(fdr_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, int64_t n_reads, int32_t k,
                    int64_t min_count, int64_t *n_out);
 int fdr_kmer_count_fetch(fdr_ctx *ctx, uint64_t *codes_out, uint64_t *counts_out);
+/* The same in pieces, for a reader that streams the reads (the reference pipes them through jellyfish,
+ * count_kmers.py:80-99) and never holds the whole read set: begin, add whole reads any number of times (seq_off[0] = 0
+ * in every piece), finish = fdr_kmer_count's threshold and result; then fdr_kmer_count_fetch. */
+int fdr_kmer_count_begin(fdr_ctx *ctx, int32_t k);
+int fdr_kmer_count_add(fdr_ctx *ctx, const uint8_t *seqs, const int64_t *seq_off, int64_t n_reads);
+int fdr_kmer_count_finish(fdr_ctx *ctx, int64_t min_count, int64_t *n_out);
 int fdr_set_kmer_count_block(fdr_ctx *ctx, int64_t chars);
 int fdr_last_kmer_count_blocks(fdr_ctx *ctx);
 

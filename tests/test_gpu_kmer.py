@@ -159,6 +159,43 @@ def test_kmer_count_in_blocks(ctx, oracle, k, min_count, block):
     assert np.array_equal(many[0], wc) and np.array_equal(many[1], wn)
 
 
+def test_streamed_counting_and_search_equal_the_one_piece_calls(ctx, oracle, tmp_path):
+    """The pipeline streams the reads (iter_sequence_blocks): counting in pieces (fdr_kmer_count_begin / _add /
+    _finish) equals the one-piece call and the oracle; kmer_searcher fed in pieces writes the bytes the one-piece
+    writer writes and returns the same CSR."""
+    s = synth_sequences(600, genome_len=60_000, mean_len=1500, k=15, sample=0.05, seed=91)
+    reads = _reads(s["seqs"], s["seq_off"])
+    fa = tmp_path / "reads.fasta"
+    fa.write_bytes(b"".join(b">%s\n%s\n" % (i, r) for i, r in zip(s["ids"], reads)))
+    k = 15
+    one = ctx.kmer_count(s["seqs"], s["seq_off"], k, 2)
+    ctx.kmer_count_begin(k)
+    pieces = 0
+    for _, seqs, off in ks.iter_sequence_blocks(str(fa), chunk_bytes=50_000):
+        ctx.kmer_count_add(seqs, off)
+        pieces += 1
+    many = ctx.kmer_count_finish(2)
+    assert pieces > 5
+    wc, wn = oracle.kmer_count(reads, k, 2)
+    assert np.array_equal(one[0], wc) and np.array_equal(one[1], wn)
+    assert np.array_equal(many[0], wc) and np.array_equal(many[1], wn)
+    with pytest.raises(_lib.FedrannHipError):
+        ctx.kmer_count_add(s["seqs"], s["seq_off"])  # (no begin)
+    lib = tmp_path / "lib.txt"
+    lib.write_bytes(b"\n".join(s["fwd"] + s["rev"]) + b"\n")
+    ids, ip, ix, n_lib = ks.kmer_searcher(str(lib), str(fa), str(tmp_path / "a"), k, context=ctx)
+    n_reads, none, nnz, n_lib2 = ks.kmer_searcher(str(lib), str(fa), str(tmp_path / "b"), k, context=ctx, collect=False,
+                                                chunk_bytes=40_000)
+    assert (n_reads, none, nnz, n_lib2) == (600, None, ix.size, n_lib) and ids == s["ids"]
+    ks.write_output_bin(str(tmp_path / "whole.bin"), ids, ip, ix)
+    ks.write_kmer_frequency_bin(str(tmp_path / "whole_freq.bin"), ix, n_lib)
+    for d in ("a", "b"):
+        assert (tmp_path / d / "output.bin").read_bytes() == (tmp_path / "whole.bin").read_bytes()
+        assert (tmp_path / d / "kmer_frequency.bin").read_bytes() == (tmp_path / "whole_freq.bin").read_bytes()
+    wp, wx = oracle.kmer_search(reads, oracle.kmer_library(lib.read_bytes(), k), k)
+    assert np.array_equal(ip, wp) and np.array_equal(ix, wx)
+
+
 def test_run_kmer_searcher_from_reads_only(ctx, oracle, tmp_path):
     """count_kmers.run_kmer_searcher: FASTA in; library files, output.bin out; same return tuple as the
     reference.  The library equals the thresholded canonical counts filtered by the documented sampler."""

@@ -101,3 +101,51 @@ def test_kmer_search_oracle_quirks(oracle):
     ip, ix = oracle.kmer_search([b"ACGT", b"", b"AC", b"ANTTTA", b"acgt", b"NA"], codes, 3)
     assert ip.tolist() == [0, 2, 3, 4, 5, 7, 7]
     assert ix.tolist() == [0, 1, 4, 3, 2, 0, 1]
+
+
+def _mixed_fasta(rng, n):
+    out = [b"junk before the first header\n"]
+    for i in range(n):
+        name = b"" if i % 37 == 5 else b"r%d desc\tx" % i
+        seq = bytes(rng.choice(list(b"ACGTN"), size=int(rng.integers(0, 400))).astype(np.uint8))
+        out.append(b">" + name + b"\n")
+        for j in range(0, len(seq), 70):
+            out.append(seq[j:j + 70] + (b"\r\n" if i % 50 == 3 else b"\n"))
+            if i % 11 == 0:
+                out.append(b"\n")
+    return b"".join(out)
+
+
+def _mixed_fastq(rng, n):
+    out = []
+    for i in range(n):
+        name = b"q%d extra" % i if i % 9 else b"q%d" % i
+        seq = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 300))).astype(np.uint8))
+        out.append(b"@" + name + b"\n" + seq + b"\n+\n" + b"@" * len(seq) + b"\n")  # quality lines that start with '@'
+        if i % 13 == 0:
+            out.append(b"\n")
+    return b"".join(out)[:-1]  # no newline at the end of the file
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fastq"])
+@pytest.mark.parametrize("ids_as_fasta", [False, True])
+def test_streaming_reader_equals_whole_file_reader(tmp_path, kind, ids_as_fasta):
+    """iter_sequence_blocks (what the pipeline uses: the read set never sits in host memory) yields the records
+    of read_sequences, whatever the piece size -- pieces smaller than a record, records with empty names, CRs,
+    empty lines, text before the first header, FASTQ quality lines starting with '@', no final newline."""
+    rng = np.random.default_rng(1)
+    p = tmp_path / ("reads." + kind)
+    p.write_bytes((_mixed_fasta if kind == "fasta" else _mixed_fastq)(rng, 500))
+    ids, seqs, off = ks.read_sequences(str(p), fastq_ids_as_fasta=ids_as_fasta)
+    assert len(ids) > 400
+    for chunk in (64, 1000, 4096, 1 << 20):
+        got_ids, got_seqs, got_off = [], [], [0]
+        for a, b, c in ks.iter_sequence_blocks(str(p), fastq_ids_as_fasta=ids_as_fasta, chunk_bytes=chunk):
+            got_ids += a
+            got_seqs.append(b)
+            got_off += (c[1:] + got_off[-1]).tolist()
+        assert got_ids == ids
+        assert np.array_equal(np.concatenate(got_seqs), seqs) and np.array_equal(np.array(got_off), off)
+    empty = tmp_path / "empty.fa"
+    empty.write_bytes(b"")
+    assert list(ks.iter_sequence_blocks(str(empty))) == []
