@@ -877,7 +877,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                                dp, d_hqc, d_thetac, d_cnt);
             HIP_TRY(hipGetLastError());
             const KnnPlan rp = knn_plan(ctx->num_cus, c, nt, d, 1, range_shape(dp));  // (k = 1: ring-only LDS)
-            const size_t rlds = (size_t)RANGE_STAGES * 32 * 256;
+            const size_t rlds = (size_t)RANGE_STAGES * 32 * 256 + (size_t)RANGE_LANE_BUF * 256 * 4;  // ring + lane buffers
 #define FDR_LAUNCH_RANGE(DP_, WPS_)                                                                     \
     hipLaunchKernelGGL((knn_range_kernel<DP_, 4, WPS_>), dim3((unsigned)rp.nqb, (unsigned)rp.nseg),        \
                        dim3(256), rlds, st, (const _Float16 *)d_hqc, (const float *)d_thetac, c,          \
