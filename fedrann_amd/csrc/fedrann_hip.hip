@@ -627,18 +627,38 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
     const KnnShape &sh = kShapes[p.shape];
     const size_t lds = knn_lds_bytes(sh, k);
     if (lds > 160 * 1024) return fail(FDR_E_ARG, "knn: k=%d, d=%d needs %zu B of LDS (> 160 KiB)", k, d, lds);
-    dim3 grid((unsigned)p.nqb, (unsigned)p.nseg);
     const int dbg = dev_knobs().debug;  // (development builds only; 0 in the release library)
     (void)dbg;
+    // the nqb * nseg work items in one launch, or (p.cohort > 0: knn_plan_compute) in synchronised rounds dealt to
+    // p.queues queues, like the prefilter pass
+    const long long n_items = (long long)p.nqb * p.nseg;
+    const long long per_launch = p.cohort > 0 ? p.cohort : n_items;
+    const int nqueues = p.cohort > 0 && n_items > per_launch ? std::max(1, std::min(p.queues, 2)) : 1;
+    hipStream_t qs[2] = {st, st};
+    if (nqueues > 1) {
+        if (!ctx->aux_ev[0]) {
+            for (hipStream_t &a : ctx->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+            for (hipEvent_t &e : ctx->aux_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        qs[1] = ctx->aux_stream[0];
+    }
     int trc = timing_begin(ctx, FDR_KERNEL_KNN_TILE, st);
     if (trc) return trc;
+    if (nqueues > 1) {
+        HIP_TRY(hipEventRecord(ctx->aux_ev[0], st));
+        HIP_TRY(hipStreamWaitEvent(qs[1], ctx->aux_ev[0], 0));
+    }
 #define FDR_LAUNCH_KNN(DP_, NQ_, NW_, WPS_)                                                          \
     do {                                                                                             \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel<DP_, NQ_, NW_, WPS_>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
-        hipLaunchKernelGGL((knn_tile_kernel<DP_, NQ_, NW_, WPS_>), grid, dim3(64 * NW_), lds, st, d_Qhat, \
-                           d_qzero, (int)nq, d_That, d_bits, (int)nt, (int)t_base, p.segs, k,        \
-                           p.nq_pad, d_partial, d_shared, knn_qcap(sh, k) FDR_DBG_ARG(dbg));        \
+        int li_ = 0;                                                                                 \
+        for (long long base_ = 0; base_ < n_items; base_ += per_launch, ++li_)                       \
+            hipLaunchKernelGGL((knn_tile_kernel<DP_, NQ_, NW_, WPS_>),                               \
+                               dim3((unsigned)std::min(per_launch, n_items - base_)), dim3(64 * NW_), lds, \
+                               qs[li_ % nqueues], d_Qhat, d_qzero, (int)nq, d_That, d_bits, (int)nt, (int)t_base, \
+                               p.segs, k, p.nq_pad, d_partial, d_shared, knn_qcap(sh, k), (int)base_, p.nqb \
+                               FDR_DBG_ARG(dbg));                                                    \
     } while (0)
     switch (p.shape) {
         case 0: FDR_LAUNCH_KNN(128, 1, 4, 3); break;
@@ -649,6 +669,10 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
     }
 #undef FDR_LAUNCH_KNN
     HIP_TRY(hipGetLastError());
+    if (nqueues > 1) {
+        HIP_TRY(hipEventRecord(ctx->aux_ev[1], qs[1]));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_ev[1], 0));
+    }
 #ifdef FDR_DEBUG_COUNTERS
     if (dbg & 2) {
         unsigned long long c[8];
