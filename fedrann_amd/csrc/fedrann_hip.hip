@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <type_traits>
+#include <utility>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
@@ -826,6 +827,8 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             if (sh.nw == 8) FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512);
             else FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
         } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
+        else if (dp == 256 && sh.tps == 8 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 2, 4);
+        else if (dp == 512 && sh.tps == 8 && sh.nw == 8) FDR_LAUNCH_PRE(512, 1, 8, 2, 4);
         else if (dp == 256 && sh.tps == 8) FDR_LAUNCH_PRE(256, 1, 4, 2, 4);
         else if (dp == 512 && sh.tps == 8) FDR_LAUNCH_PRE(512, 1, 4, 2, 4);
         else if (dp == 256 && sh.wps == 2 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 2, 2);
