@@ -64,6 +64,29 @@ static int cmd_loader(const char *path, long long F, int threads, bool stale) {
     return 0;
 }
 
+// records [lo, hi) through the ranged loader, arrays sized EXACTLY (an overrun is an ASan report)
+static int cmd_loader_range(const char *path, long long F, int threads, long long lo, long long hi, int with_names) {
+    int64_t R = 0, nnz = 0, nb = 0;
+    int rc = fdr_kmer_output_scan_range(path, lo, hi, &R, &nnz, &nb);
+    if (rc) {
+        printf("rc=%d err=%s\n", rc, g_err);
+        return 0;
+    }
+    std::vector<int64_t> indptr((size_t)(2 * (hi - lo) + 1)), name_off(with_names ? (size_t)(R + 1) : 0);
+    std::vector<int32_t> indices((size_t)(2 * nnz));
+    std::vector<char> names(with_names ? (size_t)nb : 0);
+    rc = fdr_kmer_output_load_range(path, F, threads, R, lo, hi, nnz, nb, indptr.data(), indices.data(),
+                                    with_names ? name_off.data() : nullptr, with_names ? names.data() : nullptr);
+    if (rc) {
+        printf("rc=%d err=%s\n", rc, g_err);
+        return 0;
+    }
+    printf("rc=0 R=%lld nnz=%lld sums=%llu,%llu,%llu,%llu\n", (long long)R, (long long)nnz,
+           (unsigned long long)wsum(indptr), (unsigned long long)wsum(indices), (unsigned long long)wsum(name_off),
+           (unsigned long long)wsum(names));
+    return 0;
+}
+
 static int cmd_tables(unsigned seed, long long F, int d) {
     std::mt19937_64 rng(seed);
     // a very sparse P: each feature row is non-empty with probability ~ d / sqrt(F) (capped), 1-3 entries
@@ -202,6 +225,8 @@ int main(int argc, char **argv) {
     const std::string cmd = argc > 1 ? argv[1] : "";
     if (cmd == "loader" && argc == 5) return cmd_loader(argv[2], atoll(argv[3]), atoi(argv[4]), false);
     if (cmd == "loader-stale" && argc == 4) return cmd_loader(argv[2], atoll(argv[3]), 2, true);
+    if (cmd == "loader-range" && argc == 8)
+        return cmd_loader_range(argv[2], atoll(argv[3]), atoi(argv[4]), atoll(argv[5]), atoll(argv[6]), atoi(argv[7]));
     if (cmd == "tables" && argc == 5) return cmd_tables((unsigned)atoi(argv[2]), atoll(argv[3]), atoi(argv[4]));
     if (cmd == "plan") return cmd_plan();
     if (cmd == "floats" && argc == 3) {  // host_san floats N: float32 bit patterns (one hex word per line on stdin) -> text
@@ -226,6 +251,8 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> strands((size_t)n);
         for (int64_t i = 0; i < n; ++i) {
             names += "read_" + std::to_string(i / 2) + std::string((size_t)(rng() % 5), 'x');
+            if (i % 211 == 0) names += "\"q\"";  // (a name csv.QUOTE_MINIMAL quotes and doubles)
+            if (i % 307 == 0) names += "\tz";
             off[(size_t)i + 1] = (int64_t)names.size();
             strands[(size_t)i] = (uint8_t)(i & 1);
         }
@@ -236,6 +263,7 @@ int main(int argc, char **argv) {
             const uint32_t bits = (uint32_t)(rng() % 0x3f800001u);  // [0, 1]
             memcpy(&dist[(size_t)i], &bits, 4);
             if (rng() % 97 == 0) dist[(size_t)i] = std::numeric_limits<float>::infinity();
+            if (rng() % 389 == 0) dist[(size_t)i] = std::numeric_limits<float>::quiet_NaN();  // (an empty field)
         }
         for (int64_t q = 0; q < n; q += 3) idx[(size_t)(q * k)] = (int32_t)q;
         int64_t lines = 0, lines2 = 0;

@@ -91,6 +91,27 @@ def test_loader_under_sanitizers_matches_library(san, tmp_path, threads):
     assert [int(x) for x in f["sums"].split(",")] == [_wsum(indptr), _wsum(indices), _wsum(name_off), _wsum(names)]
 
 
+def test_ranged_loader_under_sanitizers_matches_library(san, tmp_path):
+    """fdr_kmer_output_scan_range / _load_range (a rank's row block) with exactly sized arrays: the sanitized build's
+    sums equal the library's for a middle block, the first record, an empty block and the whole file; with and
+    without names; a block past the end is refused."""
+    rng = np.random.default_rng(8)
+    L, R = 9000, 5000
+    blob = [_hdr(b"KMER", 1, R)]
+    for i in range(R):
+        n = 0 if i % 89 == 0 else int(rng.integers(1, 80))
+        blob.append(_rec(b"r%d" % i, rng.choice(2 * L, size=n, replace=False).tolist()))
+    p = tmp_path / "output.bin"
+    p.write_bytes(b"".join(blob))
+    for lo, hi, names in ((1200, 3456, 1), (0, 1, 1), (77, 77, 1), (0, R, 1), (4000, R, 0)):
+        f = _fields(san("loader-range", p, 2 * L, 3, lo, hi, names))
+        total, ip, ix, noff, nbuf = _lib.kmer_output_load_range(str(p), 2 * L, lo, hi, n_threads=3, with_names=bool(names))
+        assert f["rc"] == "0" and int(f["R"]) == R == total
+        want = [_wsum(ip), _wsum(ix), _wsum(noff) if names else 0, _wsum(nbuf) if names else 0]
+        assert [int(x) for x in f["sums"].split(",")] == want
+    assert int(_fields(san("loader-range", p, 2 * L, 1, 10, R + 1, 1))["rc"]) == -1
+
+
 def test_loader_errors_under_sanitizers_match_library(san, tmp_path):
     """Every malformed file of tests/test_host.py::test_native_output_bin_loader_errors: same return code
     from the sanitized build as from the library, and no out-of-bounds access on the way."""
