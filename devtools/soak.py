@@ -16,9 +16,9 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = _lib.Context(0)
 bad = 0
 for c in range(cases):
-    n = int(rng.choice([9000, 17000, 33000, 70000, 150000, 300000]))  # (>= 131073 rows: synchronised rounds, two queues)
-    d = int(rng.choice([64, 128, 128, 200, 256, 500]))
-    k = int(rng.choice([5, 20, 20, 33, 50, 56, 64]))
+    n = int(rng.choice([9000, 17000, 33000, 70000, 150000, 300000, 450000]))  # (>= 131073 rows: synchronised rounds, two queues)
+    d = int(rng.choice([64, 128, 128, 200, 256, 256, 500]))
+    k = int(rng.choice([5, 20, 20, 24, 33, 50, 50, 56, 64]))
     kind = int(rng.integers(0, 4))
     if kind == 0:    # sparse rows like real embeddings
         E = rng.standard_normal((n, d)).astype(np.float32)

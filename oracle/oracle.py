@@ -11,6 +11,8 @@ Pinned against the reference's own outputs (tests/golden/, made by tests/golden/
     overlaps_tsv       <- __main__.py:261-300, :385         PINNED (overlaps_{edge,rand}.tsv)
     knn                <- nearest_neighbors.py:39-55        PARITY UNPINNED (pynndescent absent; see
                           the header of fedrann_oracle.c)
+    nndescent          <- the same call, as the ALGORITHM pynndescent runs (nndescent.c: RP forest + NN-descent
+                          restated from its published description): CPU baseline and recall figure only
     read_sequences / kmer_library / kmer_search
                        <- kmer_searcher/kmer_searcher.cpp   PARITY UNPINNED (needs the un-vendored
                           robin_hood.h; its own test data pin an obsolete format)
@@ -49,6 +51,8 @@ def lib():
         L.orc_knn.restype = ctypes.c_int
         L.orc_pair_dist.argtypes = [vp, vp, i32, ctypes.c_int, ctypes.c_int]
         L.orc_pair_dist.restype = ctypes.c_float
+        L.orc_nndescent.argtypes = [vp, vp, i64, i32, i32, i32, i32, ctypes.c_uint64, vp, vp, vp]
+        L.orc_nndescent.restype = ctypes.c_int
         L.orc_num_threads.restype = ctypes.c_int
         L.orc_set_num_threads.argtypes = [ctypes.c_int]
         L.orc_set_num_threads.restype = None
@@ -206,6 +210,26 @@ def knn(E, k, q_lo=0, q_hi=None):
     Eh, _, zero = normalize(E)
     q_hi = Eh.shape[0] if q_hi is None else q_hi
     return knn_normalized(Eh[q_lo:q_hi], zero[q_lo:q_hi], Eh, zero, k)
+
+
+def nndescent(Eh, zero, k, n_trees=300, leaf_size=200, seed=602):
+    """The ALGORITHM of the reference's k-NN stage (nearest_neighbors.py:39-55 -> pynndescent.NNDescent with the
+    arguments of __main__.py:184-197: angular RP forest of n_trees trees, leaf_size, NN-descent with
+    max_candidates = min(60, k), delta = 0.001, max(5, log2 N) rounds) restated in oracle/nndescent.c from its
+    published description -- the package itself is absent (PARITY UNPINNED; an approximate, randomised method).
+    Eh / zero: normalised rows and zero flags (normalize()).  Returns (idx int32 [n,k], dist float32 [n,k]
+    ascending, stats dict)."""
+    Eh = np.ascontiguousarray(Eh, dtype=np.float32)
+    zero = np.ascontiguousarray(zero, dtype=np.uint8)
+    n, d = Eh.shape
+    idx = np.empty((n, k), dtype=np.int32)
+    dist = np.empty((n, k), dtype=np.float32)
+    stats = np.zeros(3, dtype=np.int64)
+    rc = lib().orc_nndescent(_p(Eh), _p(zero), n, d, int(k), int(n_trees), int(leaf_size), int(seed), _p(idx), _p(dist),
+                             _p(stats))
+    if rc != 0:
+        raise ValueError("orc_nndescent failed (%d)" % rc)
+    return idx, dist, {"rounds": int(stats[0]), "leaves": int(stats[1]), "distance_evaluations": int(stats[2])}
 
 
 def pair_dist_normalized(a, a_zero, b, b_zero):

@@ -131,3 +131,26 @@ def test_knn_ties_and_zero_rows(oracle):
     assert idx[3, :3].tolist() == [3, 43, 89]
     assert dist[3, 0] == dist[3, 1] == dist[3, 2]
     assert idx.min() >= 0 and idx.max() < n
+
+
+def test_nndescent_restatement_approximates_the_exact_search(oracle):
+    """oracle/nndescent.c (the reference's k-NN ALGORITHM restated: RP forest + NN-descent; bench.py's second CPU
+    baseline): rows ascending by (distance, index), self at distance 0, and a tie-aware recall close to 1 against
+    the exact oracle -- with the reference's forest (300 trees, leaves of 200) and with a small one, where the
+    descent rounds have to do the work."""
+    from fedrann_amd.precompute import build_precompute_matrix
+    from fedrann_amd.synth import synth
+    s = synth(6000, seed=11, m=120)
+    P = build_precompute_matrix(s["counts"], 128)
+    E = oracle.embed(s["indptr"], s["indices"], (P.indptr, P.indices, P.data), s["n_features"], 128)
+    Eh, _, zero = oracle.normalize(E)
+    k = 20
+    _, wd = oracle.knn_normalized(Eh, zero, Eh, zero, k)
+    for trees, leaf, floor in ((300, 200, 0.999), (6, 40, 0.9)):
+        idx, dist, stats = oracle.nndescent(Eh, zero, k, n_trees=trees, leaf_size=leaf, seed=5)
+        assert idx.shape == (6000, k) and idx.min() >= 0 and idx.max() < 6000
+        assert np.all(np.diff(dist, axis=1) >= 0) and stats["rounds"] >= 1
+        nz = zero == 0
+        assert np.all((idx[nz] == np.arange(6000)[nz, None]).any(1) | (dist[nz, -1] == 0))  # self, unless k exact duplicates precede it
+        recall = float((dist <= wd[:, k - 1:k]).mean())
+        assert recall >= floor, (trees, leaf, recall)
