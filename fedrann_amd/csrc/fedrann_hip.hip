@@ -903,15 +903,20 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                                (const _Float16 *)d_hq, (const float *)d_theta, (const int *)d_rlist, first, c,
                                dp, d_hqc, d_thetac, d_cnt);
             HIP_TRY(hipGetLastError());
-            const KnnPlan rp = knn_plan(ctx->num_cus, c, nt, d, 1, range_shape(dp));  // (k = 1: ring-only LDS)
-            const size_t rlds = (size_t)RANGE_STAGES * 32 * 256 + (size_t)RANGE_LANE_BUF * 256 * 4;  // ring + lane buffers
-#define FDR_LAUNCH_RANGE(DP_, WPS_)                                                                     \
-    hipLaunchKernelGGL((knn_range_kernel<DP_, 4, WPS_>), dim3((unsigned)rp.nqb, (unsigned)rp.nseg),        \
-                       dim3(256), rlds, st, (const _Float16 *)d_hqc, (const float *)d_thetac, c,          \
+            // (d <= 128, many plateau queries -- 99 k of 916 k at config 4: eight waves per workgroup, half the LDS-DMA
+            // pieces per flop, as in the candidate pass)
+            const int r8 = dev_knobs().range8;
+            const bool wide = dp == 128 && (r8 == 1 || (r8 < 0 && rcount >= 65536));
+            const KnnPlan rp = knn_plan(ctx->num_cus, c, nt, d, 1, wide ? FDR_SHAPE_PREFILTER_W8 : range_shape(dp));  // (k = 1: ring-only LDS)
+            const size_t rlds = (size_t)RANGE_STAGES * 32 * 256 + (size_t)RANGE_LANE_BUF * (wide ? 512 : 256) * 4;  // ring + lane buffers
+#define FDR_LAUNCH_RANGE(DP_, NW_, WPS_)                                                                \
+    hipLaunchKernelGGL((knn_range_kernel<DP_, NW_, WPS_>), dim3((unsigned)rp.nqb, (unsigned)rp.nseg),      \
+                       dim3(64 * NW_), rlds, st, (const _Float16 *)d_hqc, (const float *)d_thetac, c,     \
                        (const _Float16 *)d_ht, (int)nt, (int)t_base, rp.segs, d_cnt, d_rcand)
-            if (dp == 128) FDR_LAUNCH_RANGE(128, 4);
-            else if (dp == 256) FDR_LAUNCH_RANGE(256, 2);
-            else FDR_LAUNCH_RANGE(512, 2);
+            if (wide) FDR_LAUNCH_RANGE(128, 8, 4);
+            else if (dp == 128) FDR_LAUNCH_RANGE(128, 4, 4);
+            else if (dp == 256) FDR_LAUNCH_RANGE(256, 4, 2);
+            else FDR_LAUNCH_RANGE(512, 4, 2);
 #undef FDR_LAUNCH_RANGE
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(knn_rerank_long_kernel, dim3((unsigned)((c + 3) / 4)), dim3(256), 0, st,
