@@ -827,6 +827,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             if (sh.nw == 8) FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512);
             else FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
         } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
+        else if (dp == 256 && sh.tps == 16 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 2, 8);
         else if (dp == 256 && sh.tps == 8 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 2, 4);
         else if (dp == 512 && sh.tps == 8 && sh.nw == 8) FDR_LAUNCH_PRE(512, 1, 8, 2, 4);
         else if (dp == 256 && sh.tps == 8) FDR_LAUNCH_PRE(256, 1, 4, 2, 4);
