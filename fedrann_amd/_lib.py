@@ -20,7 +20,8 @@ SYMBOLS = (
     "fdr_kmer_count_fetch", "fdr_set_kmer_count_block", "fdr_last_kmer_count_blocks", "fdr_csr_compact", "fdr_host_register", "fdr_host_unregister",
     "fdr_overlaps_write", "fdr_last_prefilter_launches", "fdr_knn_classes_dev", "fdr_knn_unique_dev",
     "fdr_knn_expand_dev", "fdr_kmer_output_scan_range", "fdr_kmer_output_load_range",
-    "fdr_kmer_count_begin", "fdr_kmer_count_add", "fdr_kmer_count_finish",
+    "fdr_kmer_count_begin", "fdr_kmer_count_add", "fdr_kmer_count_finish", "fdr_reads_scan", "fdr_reads_parse",
+    "fdr_kmer_output_append",
 )
 FDR_MAX_K = 128
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
@@ -95,6 +96,9 @@ def load_library():
     L.fdr_kmer_output_load.argtypes = [ctypes.c_char_p, i64, i32, i64, i64, i64, vp, vp, vp, vp]
     L.fdr_kmer_output_scan_range.argtypes = [ctypes.c_char_p, i64, i64, p64, p64, p64]
     L.fdr_kmer_output_load_range.argtypes = [ctypes.c_char_p, i64, i32, i64, i64, i64, i64, i64, vp, vp, vp, vp]
+    L.fdr_kmer_output_append.argtypes = [ctypes.c_char_p, i64, vp, vp, vp, vp]
+    L.fdr_reads_scan.argtypes = [vp, i64, i32, i32, i32, p64, p64, p64]
+    L.fdr_reads_parse.argtypes = [vp, i64, i32, i32, i64, i64, vp, vp, vp]
     L.fdr_csr_compact.argtypes = [vp, i64, vp, vp, vp, vp, i64, i32]
     L.fdr_host_register.argtypes = [vp, vp, sz]
     L.fdr_host_unregister.argtypes = [vp, vp]
@@ -176,6 +180,48 @@ def kmer_output_load_range(path, n_features, rec_lo, rec_hi, n_threads=0, with_n
     if rc != 0:
         raise FedrannHipError("fdr_kmer_output_load_range failed (%d): %s" % (rc, L.fdr_last_error().decode()))
     return R.value, indptr, indices, name_off, names
+
+
+def reads_parse(buf, n, is_fastq, fastq_ids_as_fasta, eof, seq_buf=None):
+    """Whole records in buf[:n] (uint8 array: the tail of the previous piece of a FASTA / FASTQ file + new bytes)
+    -> (consumed bytes, ids list of bytes, seqs uint8, seq_off int64 [R + 1]) through fdr_reads_scan /
+    fdr_reads_parse (host only, no GPU).  seq_buf: a uint8 array of at least n bytes to hold the sequences (seqs is
+    then a view of it) instead of a fresh one."""
+    L = load_library()
+    used, R, nb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    base = buf.ctypes.data if n else None
+    rc = L.fdr_reads_scan(base, int(n), int(bool(is_fastq)), int(bool(fastq_ids_as_fasta)), int(bool(eof)),
+                          ctypes.byref(used), ctypes.byref(R), ctypes.byref(nb))
+    if rc != 0:
+        raise FedrannHipError("fdr_reads_scan failed (%d): %s" % (rc, L.fdr_last_error().decode()))
+    seqs = np.empty(nb.value, dtype=np.uint8) if seq_buf is None else seq_buf[:nb.value]
+    off = np.empty(R.value + 1, dtype=np.int64)
+    span = np.empty(2 * R.value, dtype=np.int64)
+    rc = L.fdr_reads_parse(base, used.value, int(bool(is_fastq)), int(bool(fastq_ids_as_fasta)), R.value, nb.value,
+                           seqs.ctypes.data if nb.value else None, off.ctypes.data, span.ctypes.data if R.value else None)
+    if rc != 0:
+        raise FedrannHipError("fdr_reads_parse failed (%d): %s" % (rc, L.fdr_last_error().decode()))
+    view = memoryview(buf)
+    sp = span.tolist()
+    ids = [bytes(view[sp[2 * r]:sp[2 * r + 1]]) for r in range(R.value)]
+    return used.value, ids, seqs, off
+
+
+def kmer_output_append(path, ids, indptr, indices):
+    """Records of output.bin appended to `path` (fdr_kmer_output_append; host only).  ids: list of bytes."""
+    L = load_library()
+    name_off, names = pack_names(ids)
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    if indptr.size != len(ids) + 1:
+        raise ValueError("indptr must have one entry per record + 1")
+    rc = L.fdr_kmer_output_append(os.fsencode(path), len(ids), _ptr(name_off), _ptr(names) if names.size else None,
+                                  _ptr(indptr), _ptr(indices) if indices.size else None)
+    if rc != 0:
+        msg = L.fdr_last_error().decode()
+        if "non-ASCII" in msg or "bytes long" in msg:
+            raise ValueError(msg)
+        raise FedrannHipError("fdr_kmer_output_append failed (%d): %s" % (rc, msg))
 
 
 def pack_names(read_names):

@@ -21,7 +21,7 @@ from os.path import join
 import numpy as np
 
 from . import _lib, global_variables
-from .kmer_search import iter_sequence_blocks, kmer_searcher
+from .kmer_search import iter_sequence_blocks, kmer_searcher, unique_first
 
 _BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
 
@@ -47,15 +47,50 @@ def sample_kmers(n, sample_fraction, seed):
     return np.flatnonzero(rng.random(int(n)) > 1.0 - float(sample_fraction))
 
 
+def revcomp_codes(codes, k):
+    """2-bit codes of the reverse complements (what `seqkit seq -r -p` makes of each library k-mer)."""
+    c = np.asarray(codes, dtype=np.uint64) ^ np.uint64((1 << (2 * k)) - 1)  # complement: A<->T, C<->G = 3 - base
+    out = np.zeros_like(c)
+    for _ in range(k):
+        out = (out << np.uint64(2)) | (c & np.uint64(3))
+        c = c >> np.uint64(2)
+    return out
+
+
+def kmer_library_text(codes, counts, k):
+    """jellyfish-dump style FASTA as one uint8 array: '>count' then the k-mer, a line each."""
+    counts = np.asarray(counts, dtype=np.uint64)
+    n = counts.size
+    nd = np.ones(n, dtype=np.int64)  # decimal digits of each count
+    p = np.uint64(10)
+    for _ in range(19):
+        more = counts >= p
+        if not more.any():
+            break
+        nd += more
+        p = p * np.uint64(10)
+    rec = nd + (k + 3)  # '>' digits '\n' k-mer '\n'
+    start = np.zeros(n, dtype=np.int64)
+    np.cumsum(rec[:-1], out=start[1:])
+    out = np.empty(int(rec.sum()), dtype=np.uint8)
+    out[start] = ord(">")
+    rest = counts.copy()
+    for j in range(int(nd.max()) if n else 0):  # digit j from the right
+        m = nd > j
+        out[(start + nd - j)[m]] = (48 + rest[m] % np.uint64(10)).astype(np.uint8)
+        rest //= np.uint64(10)
+    out[start + nd + 1] = 10
+    kmers = codes_to_kmers(codes, k)
+    for j in range(k):
+        out[start + nd + 2 + j] = kmers[:, j]
+    out[start + nd + 2 + k] = 10
+    return out
+
+
 def write_kmer_library(path, codes, counts, k):
     """jellyfish-dump style FASTA: '>count' then the k-mer (count_kmers.py:119-121; read back by
     precompute.py:44-55)."""
-    kmers = codes_to_kmers(codes, k)
-    with open(path, "wb", buffering=1 << 24) as f:
-        for c, row in zip(np.asarray(counts).tolist(), kmers):
-            f.write(b">%d\n" % c)
-            f.write(row.tobytes())
-            f.write(b"\n")
+    kmer_library_text(codes, counts, k).tofile(path)
 
 
 def run_kmer_searcher(input_path, k, sample_fraction, min_multiplicity=2, context=None):
@@ -79,19 +114,20 @@ def run_kmer_searcher(input_path, k, sample_fraction, min_multiplicity=2, contex
     # (fastq_ids_as_fasta: the reference runs seqkit fq2fa first)
     ctx = context or _lib.default_context()
     ctx.kmer_count_begin(int(k))
-    for _, seqs, off in iter_sequence_blocks(input_path, fastq_ids_as_fasta=True):
+    for _, seqs, off in iter_sequence_blocks(input_path, fastq_ids_as_fasta=True, reuse_buffers=True):
         ctx.kmer_count_add(seqs, off)
     codes, counts = ctx.kmer_count_finish(int(min_multiplicity))
     keep = sample_kmers(codes.size, sample_fraction, global_variables.seed)
     fwd = join(tmp, "fwd_kmer_library.fasta")
     write_kmer_library(fwd, codes[keep], counts[keep], k)
     kmer_count = int(keep.size)
-    comp = bytes.maketrans(b"ACGT", b"TGCA")
     rev = join(tmp, "rev_kmer_library.fasta")
-    with open(fwd, "rb") as f, open(rev, "wb") as g:
-        for line in f:
-            g.write(line if line.startswith(b">") else line.rstrip(b"\n").translate(comp)[::-1] + b"\n")
+    rev_codes = revcomp_codes(codes[keep], k)  # (seqkit seq -r -p: same headers, same order)
+    write_kmer_library(rev, rev_codes, counts[keep], k)
     out_dir = join(tmp, "kmer_searcher")
+    # the library as `cat fwd rev | grep -v '^>'` reads: forward k-mers then their reverse complements, a k-mer seen
+    # before (a palindrome) loses its second slot -- from the codes at hand instead of the two files just written
+    lib_codes = unique_first(np.concatenate((codes[keep], rev_codes)))
     n_reads, _, _, _ = kmer_searcher([fwd, rev], input_path, out_dir, k, context=context, fastq_ids_as_fasta=True,
-                                     collect=False)
+                                     collect=False, lib_codes=lib_codes)
     return join(out_dir, "output.bin"), kmer_count * 2, n_reads

@@ -869,7 +869,9 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     int *d_rlist = reinterpret_cast<int *>(ws + L.off_rlist);
     float *d_theta = reinterpret_cast<float *>(ws + L.off_theta);
     const float margin = 2.0f * prefilter_eps(ib) + 4.0e-7f;
-    hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_rerank_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, RERANK_LDS_BYTES));
+    hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), RERANK_LDS_BYTES, st,
                        (const u64 *)d_cand, kp, k, d_Qhat, d_qzero, d_That, (int)nq, dp, (int)t_base, margin,
                        d_idx, d_dist, d_counter, d_flagged, d_rlist, d_theta);
     {   // all-zero queries share one closed-form answer (their number is only known on the device yet)
@@ -990,8 +992,10 @@ static DedupLayout dedup_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int 
     L.inner_bytes = align256(knn_mode_workspace_bytes(ctx, nq, nt, d, k));
     size_t o = L.inner_bytes;
     auto take = [&](size_t bytes) { const size_t at = o; o += align256(bytes); return at; };
-    L.off_hash = take((size_t)nt * 8);
-    L.off_hash_s = take((size_t)nt * 8);
+    // (one block: the sorted hashes follow the unsorted ones, and the (representative, size, start) table of
+    // expand_classes_kernel, 16 bytes per unique row, takes the place of both once the classes are marked)
+    L.off_hash = take(align256((size_t)nt * 8) + (size_t)nt * 8);
+    L.off_hash_s = L.off_hash + align256((size_t)nt * 8);
     L.off_idx = take((size_t)nt * 4);
     L.off_idx_s = take((size_t)nt * 4);
     L.off_flag = take((size_t)nt * 4);
@@ -1114,8 +1118,9 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
                        (const int *)cid, (const int *)idx_s, cls, cstart, isrep);
     tb = L.tmp_bytes;
     HIP_TRY(rocprim::inclusive_scan(tmp, tb, isrep, upos, (size_t)n, rocprim::plus<int>(), st));
+    // (rep_m takes the hashes' place: nothing reads them once the classes are marked)
     hipLaunchKernelGGL(unique_tables_kernel, dim3(g1), dim3(256), 0, st, n, (const int *)isrep,
-                       (const int *)upos, (const int *)cls, uofc, cofu);
+                       (const int *)upos, (const int *)cls, (const int *)cstart, uofc, cofu, (int4 *)hash);
     HIP_TRY(hipMemsetAsync(uqflag, 0, (size_t)n * 4, st));
     hipLaunchKernelGGL(mark_query_classes_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, q0,
                        (int)nq, (const int *)cls, (const int *)uofc, uqflag);
@@ -1154,11 +1159,10 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
                              L.inner_bytes, st);
     if (rc) return rc;
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_DEDUP, st))) return trc;
-    const int xw = expand_waves_per_block(k);
-    hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)((nq + xw - 1) / xw)), dim3(64 * xw), (size_t)xw * k * k * 8, st, q0, (int)nq, k, (int)t_base,
-                       (const int *)cls, (const int *)uofc, (const int *)uqpos, (const int *)idx_u,
-                       (const float *)dist_u, (const int *)cofu, (const int *)cstart, (const int *)idx_s, d_idx,
-                       d_dist, k);
+    const int xw = expand_waves_per_block(k), xq = xw * (64 / k) * EXPAND_UNROLL;  // (k <= FDR_FAST_MAX_K = 64 here)
+    hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)((nq + xq - 1) / xq)), dim3(64 * xw), (size_t)xw * k * k * 8, st, q0, (int)nq, k, 64 / k,
+                       (int)t_base, (const int *)cls, (const int *)uofc, (const int *)uqpos, (const int *)idx_u,
+                       (const float *)dist_u, (const int *)idx_s, (const int4 *)hash, d_idx, d_dist, k);
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
 }
@@ -1220,7 +1224,7 @@ FDR_EXPORT int fdr_knn_classes_dev(fdr_ctx *ctx, const float *d_That, const uint
     tb = L.tmp_bytes;
     HIP_TRY(rocprim::inclusive_scan(tmp, tb, isrep, upos, (size_t)n, rocprim::plus<int>(), st));
     hipLaunchKernelGGL(unique_tables_kernel, dim3(g1), dim3(256), 0, st, n, (const int *)isrep, (const int *)upos,
-                       (const int *)cls, uofc, cofu);
+                       (const int *)cls, (const int *)cstart, uofc, cofu, (int4 *)hash);  // (rep_m over the hashes)
     HIP_TRY(hipGetLastError());
     int nu = 0;
     HIP_TRY(hipMemcpyAsync(&nu, cid + (n - 1), 4, hipMemcpyDeviceToHost, st));
@@ -1285,12 +1289,11 @@ FDR_EXPORT int fdr_knn_expand_dev(fdr_ctx *ctx, int64_t q0, int64_t nq, int64_t 
     char *ws = static_cast<char *>(ctx->cls.ws);
     int trc = timing_begin(ctx, FDR_KERNEL_KNN_DEDUP, st);
     if (trc) return trc;
-    const int xw = expand_waves_per_block(k);
-    hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)((nq + xw - 1) / xw)), dim3(64 * xw), (size_t)xw * k * k * 8, st, (int)q0, (int)nq, k,
-                       (int)t_base, (const int *)(ws + L.off_cls), (const int *)(ws + L.off_uofc), (const int *)nullptr,
-                       (const int *)d_idx_u_all, d_dist_u_all, (const int *)(ws + L.off_cofu),
-                       (const int *)(ws + L.off_cstart), (const int *)(ws + L.off_idx_s), d_idx, d_dist,
-                       (int)u_row_stride);
+    const int xw = expand_waves_per_block(k), xq = xw * (64 / k) * EXPAND_UNROLL;
+    hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)((nq + xq - 1) / xq)), dim3(64 * xw), (size_t)xw * k * k * 8, st, (int)q0, (int)nq, k,
+                       64 / k, (int)t_base, (const int *)(ws + L.off_cls), (const int *)(ws + L.off_uofc), (const int *)nullptr,
+                       (const int *)d_idx_u_all, d_dist_u_all, (const int *)(ws + L.off_idx_s),
+                       (const int4 *)(ws + L.off_hash), d_idx, d_dist, (int)u_row_stride);
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
 }
@@ -1420,4 +1423,5 @@ FDR_EXPORT int fdr_embed_knn(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indp
 
 #include "kmer_search.inc"
 #include "kmer_output_loader.inc"
+#include "reads_parser.inc"
 #include "overlaps_writer.inc"

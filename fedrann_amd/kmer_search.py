@@ -52,7 +52,12 @@ def load_kmer_library(texts, k):
         c = _CODE[data[start + j]]
         valid &= c != 255
         codes = (codes << np.uint64(2)) | (c & 3).astype(np.uint64)
-    codes = codes[valid]
+    return unique_first(codes[valid])
+
+
+def unique_first(codes):
+    """The distinct codes in order of first occurrence (a k-mer seen before loses: kmer_searcher.cpp:274-277)."""
+    codes = np.asarray(codes, dtype=np.uint64)
     _, first = np.unique(codes, return_index=True)
     first.sort()
     return np.ascontiguousarray(codes[first])
@@ -69,7 +74,8 @@ def fasta_id(header):
 
 
 def _parse_records(raw, is_fastq, fastq_ids_as_fasta):
-    """Whole records in `raw` (bytes) -> (ids, seqs uint8, seq_off int64 [R+1]); see read_sequences."""
+    """Whole records in `raw` (bytes) -> (ids, seqs uint8, seq_off int64 [R+1]); see read_sequences.  The numpy
+    statement of the reader's rules: the tests hold the native reader (fdr_reads_parse) against it."""
     data = np.frombuffer(raw, dtype=np.uint8)
     if data.size == 0:
         return [], np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64)
@@ -147,31 +153,41 @@ def _complete_prefix(raw, is_fastq, eof):
     return int(nl[-1]) + 1 if i == n else int(starts[min(i, n - 1)])
 
 
-def iter_sequence_blocks(path, fastq_ids_as_fasta=False, chunk_bytes=1 << 28):
+def iter_sequence_blocks(path, fastq_ids_as_fasta=False, chunk_bytes=1 << 28, reuse_buffers=False):
     """The records of a FASTA / FASTQ file in file order, a piece of the file at a time: yields (ids, seqs uint8,
     seq_off int64) for consecutive groups of whole records.  The reference streams its reads through pipes
     (count_kmers.py:131-139, kmer_searcher.cpp:284-292); this keeps the host at about chunk_bytes + one record
-    whatever the size of the read set.  Same records, names and sequences as read_sequences."""
-    with open(path, "rb") as f:
-        carry = f.read(chunk_bytes)
-        if not carry:
+    whatever the size of the read set.  Same records, names and sequences as read_sequences.  The bytes are read
+    into one reused buffer and cut into records by the library's native reader (fdr_reads_scan / fdr_reads_parse);
+    the unconsumed tail of a piece moves to the front of the buffer, which grows only for a record longer than it.
+    reuse_buffers: the yielded seqs are views of ONE buffer, valid until the next piece is asked for (what the
+    pipeline wants: no fresh pages per piece); default: every piece owns its arrays."""
+    chunk_bytes = max(int(chunk_bytes), 1)
+    with open(path, "rb", buffering=0) as f:
+        buf = np.empty(chunk_bytes, dtype=np.uint8)
+        have = f.readinto(memoryview(buf)) or 0
+        if have == 0:
             return
-        # (FASTQ iff the first line is non-empty and starts with '@': kmer_searcher.cpp:160-163)
-        first_nl = carry.find(b"\n")
-        first_line = carry if first_nl < 0 else carry[:first_nl]
-        is_fastq = len(first_line) > 0 and first_line[:1] == b"@"
+        is_fastq = buf[0] == ord("@")  # (a first line that is just '\n' is empty: FASTA)
+        eof = False
+        seq_buf = None
         while True:
-            more = f.read(chunk_bytes)
-            eof = len(more) == 0
-            buf = carry + more if more else carry
-            cut = _complete_prefix(buf, is_fastq, eof)
-            if cut > 0:
-                ids, seqs, off = _parse_records(buf[:cut], is_fastq, fastq_ids_as_fasta)
-                if ids:
-                    yield ids, seqs, off
-            carry = buf[cut:]
+            if not eof and have == buf.size:  # (a record longer than the buffer is waiting for its end)
+                buf = np.concatenate((buf, np.empty(max(chunk_bytes, buf.size), dtype=np.uint8)))
+            while not eof and have < buf.size:
+                got = f.readinto(memoryview(buf)[have:]) or 0
+                if got == 0:
+                    eof = True
+                have += got
+            if reuse_buffers and (seq_buf is None or seq_buf.size < have):
+                seq_buf = np.empty(buf.size, dtype=np.uint8)
+            used, ids, seqs, off = _lib.reads_parse(buf, have, is_fastq, fastq_ids_as_fasta, eof, seq_buf)
+            if ids:
+                yield ids, seqs, off
             if eof:
                 return
+            buf[:have - used] = buf[used:have]  # (numpy copies overlapping ranges safely)
+            have -= used
 
 
 def read_sequences(path, fastq_ids_as_fasta=False):
@@ -184,13 +200,11 @@ def read_sequences(path, fastq_ids_as_fasta=False):
     stays and is an invalid character); empty lines are skipped; a record whose id is empty, and anything
     before the first header, is dropped.  FASTQ: id = the whole header line after '@', sequence = the
     next line, then two lines are skipped.  (Whole file in memory: the pipeline uses iter_sequence_blocks.)"""
-    with open(path, "rb") as f:
-        raw = f.read()
-    if not raw:
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size == 0:
         return [], np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64)
-    first_nl = raw.find(b"\n")
-    first_line = raw if first_nl < 0 else raw[:first_nl]
-    return _parse_records(raw, len(first_line) > 0 and first_line[:1] == b"@", fastq_ids_as_fasta)
+    _, ids, seqs, off = _lib.reads_parse(raw, raw.size, raw[0] == ord("@"), fastq_ids_as_fasta, True)
+    return ids, seqs, off
 
 
 def search(seqs, seq_off, lib_codes, k, context=None, block_chars=1 << 31):
@@ -243,55 +257,50 @@ def write_kmer_frequency_bin(path, indices, n_lib):
     out.tofile(path)
 
 
-def _append_records(f, ids, indptr, indices):
-    """Records of output.bin (kmer_searcher.cpp:106-128) appended to the open file f."""
-    idx64 = np.asarray(indices).astype("<u8")
-    ptr = np.asarray(indptr).tolist()
-    for r, name in enumerate(ids):
-        if any(c < 32 or c > 126 for c in name):
-            raise ValueError("ID contains non-ASCII characters")
-        a, b = ptr[r], ptr[r + 1]
-        f.write(struct.pack("<H", len(name)))
-        f.write(name)
-        f.write(struct.pack("<I", b - a))
-        f.write(idx64[a:b].tobytes())
-
-
 def kmer_searcher(kmer_lib, input_reads, output_dir, k, threads=None, context=None, fastq_ids_as_fasta=False,
-                  collect=True, chunk_bytes=1 << 28):
+                  collect=True, chunk_bytes=1 << 28, lib_codes=None):
     """Drop-in for the command line `kmer_searcher <kmer_lib> <input> <output_dir> <k> <threads>`
     (kmer_searcher.cpp:232-375).  `kmer_lib`: a path, a list of paths (read in order, like
     `cat fwd rev | grep -v '^>'`; '>' header tokens are not k long and drop out by themselves unless a
     count happens to have k digits -- so, as in the reference's pipeline, header lines are removed first).
     Writes output_dir/output.bin and output_dir/kmer_frequency.bin.  The reads are STREAMED (iter_sequence_blocks):
-    a piece of the file is parsed, searched on the GPU and its records appended; the record count in the header is
-    patched at the end.  Returns (ids, indptr, indices, n_lib) -- with collect=False (the pipeline: nothing of the
+    a piece of the file is parsed (natively), searched on the GPU and its records appended (natively:
+    fdr_kmer_output_append); the record count in the header is patched at the end.  Returns (ids, indptr, indices, n_lib) -- with collect=False (the pipeline: nothing of the
     read set is kept on the host) ids is the number of reads, indptr None and indices the number of hits.
-    fastq_ids_as_fasta: see read_sequences (the pipeline's callers set it)."""
-    paths = [kmer_lib] if isinstance(kmer_lib, (str, bytes, os.PathLike)) else list(kmer_lib)
-    texts = []
-    for p in paths:
-        with open(p, "rb") as f:
-            t = f.read()
-        texts.append(b"\n".join(l for l in t.split(b"\n") if not l.startswith(b">")) + b"\n")
-    codes = load_kmer_library(texts, k)
+    fastq_ids_as_fasta: see read_sequences (the pipeline's callers set it).  lib_codes: the library as
+    load_kmer_library would return it for kmer_lib, for a caller that has just written those files and still holds
+    their k-mers (run_kmer_searcher): the files are then not read back."""
+    if lib_codes is not None:
+        if not 1 <= int(k) <= 31:
+            raise ValueError("Invalid k value: %r" % (k,))
+        codes = np.ascontiguousarray(lib_codes, dtype=np.uint64)
+    else:
+        paths = [kmer_lib] if isinstance(kmer_lib, (str, bytes, os.PathLike)) else list(kmer_lib)
+        texts = []
+        for p in paths:
+            with open(p, "rb") as f:
+                t = f.read()
+            texts.append(b"\n".join(l for l in t.split(b"\n") if not l.startswith(b">")) + b"\n")
+        codes = load_kmer_library(texts, k)
     os.makedirs(output_dir, exist_ok=True)
     freq = np.zeros(int(codes.size), dtype=np.int64)
     all_ids, ptr_parts, idx_parts, n_reads, nnz = [], [np.zeros(1, dtype=np.int64)], [], 0, 0
-    with open(os.path.join(output_dir, "output.bin"), "wb", buffering=1 << 24) as f:
+    out_bin = os.path.join(output_dir, "output.bin")
+    with open(out_bin, "wb") as f:
         f.write(struct.pack("<4sB3sQ", b"KMER", 1, b"\0\0\0", 0))
-        for ids, seqs, off in iter_sequence_blocks(input_reads, fastq_ids_as_fasta=fastq_ids_as_fasta,
-                                                   chunk_bytes=chunk_bytes):
-            indptr, indices = search(seqs, off, codes, k, context=context)
-            _append_records(f, ids, indptr, indices)
-            if indices.size:
-                freq += np.bincount(indices, minlength=freq.size)
-            if collect:
-                all_ids += ids
-                ptr_parts.append(indptr[1:] + nnz)
-                idx_parts.append(indices)
-            n_reads += len(ids)
-            nnz += int(indices.size)
+    for ids, seqs, off in iter_sequence_blocks(input_reads, fastq_ids_as_fasta=fastq_ids_as_fasta,
+                                               chunk_bytes=chunk_bytes, reuse_buffers=True):
+        indptr, indices = search(seqs, off, codes, k, context=context)
+        _lib.kmer_output_append(out_bin, ids, indptr, indices)  # (native: no per-record Python)
+        if indices.size:
+            freq += np.bincount(indices, minlength=freq.size)
+        if collect:
+            all_ids += ids
+            ptr_parts.append(indptr[1:] + nnz)
+            idx_parts.append(indices)
+        n_reads += len(ids)
+        nnz += int(indices.size)
+    with open(out_bin, "r+b") as f:  # the record count, known now
         f.seek(8)
         f.write(struct.pack("<Q", n_reads))
     nz = np.flatnonzero(freq)

@@ -240,6 +240,22 @@ int fdr_kmer_count_finish(fdr_ctx *ctx, int64_t min_count, int64_t *n_out);
 int fdr_set_kmer_count_block(fdr_ctx *ctx, int64_t chars);
 int fdr_last_kmer_count_blocks(fdr_ctx *ctx);
 
+/* ---- FASTA / FASTQ reader of the k-mer stage (host only: no context, no GPU) -------------------------
+ * Replaces read_sequences of kmer_searcher/kmer_searcher.cpp:153-200 (FASTQ iff the first line starts with '@';
+ * FASTA id = header up to the first space or tab, sequence = the following non-empty lines with only the '\n'
+ * removed, records with an empty id and anything before the first header dropped; FASTQ id = the header line
+ * after '@', sequence = the next line, two lines skipped) for a PIECE of the file: raw[0, n) = the unconsumed
+ * tail of the previous piece followed by new bytes, eof = nothing follows.  fastq_ids_as_fasta: the pipeline's
+ * `seqkit fq2fa` step (fedrann/count_kmers.py:76-79) -- FASTQ names cut like FASTA ids, empty names dropped.
+ *   fdr_reads_scan:  consumed = bytes holding whole records only (the rest waits for the next piece), their
+ *                    record count and total sequence length;
+ *   fdr_reads_parse: seqs [n_bases], seq_off int64 [n_records + 1], id_span int64 [2 n_records] = (begin, end)
+ *                    of each id inside raw; FDR_E_STATE if raw[0, consumed) no longer matches the scan. */
+int fdr_reads_scan(const uint8_t *raw, int64_t n, int32_t is_fastq, int32_t fastq_ids_as_fasta, int32_t eof,
+                   int64_t *consumed, int64_t *n_records, int64_t *n_bases);
+int fdr_reads_parse(const uint8_t *raw, int64_t consumed, int32_t is_fastq, int32_t fastq_ids_as_fasta,
+                    int64_t n_records, int64_t n_bases, uint8_t *seqs, int64_t *seq_off, int64_t *id_span);
+
 /* ---- kmer_searcher output.bin -> doubled binary CSR (host only: no context, no GPU) ---------------
  * Replaces fedrann/feature_extraction.py:108-140 (parse_kmer_searcher_output: header '<4sB3sQ' =
  * "KMER", version 1, record count; per record '<H' id length, id bytes, '<I' index count, that many
@@ -268,6 +284,14 @@ int fdr_kmer_output_scan_range(const char *path, int64_t rec_lo, int64_t rec_hi,
 int fdr_kmer_output_load_range(const char *path, int64_t n_features, int32_t n_threads, int64_t n_records,
                                int64_t rec_lo, int64_t rec_hi, int64_t nnz_range, int64_t name_bytes, int64_t *indptr,
                                int32_t *indices, int64_t *name_off, char *names);
+
+/* The writer of the same file, a group of records at a time (kmer_searcher/kmer_searcher.cpp:106-128: '<H' id
+ * length, id, '<I' count, the indices as '<Q'): appends n_records records to `path`, record r with the id
+ * names[name_off[r] .. name_off[r+1]) and the indices indices[indptr[r] .. indptr[r+1]).  Ids must be printable
+ * ASCII as there (:113-117) and at most 65535 bytes (FDR_E_ARG before anything is written).  The caller writes
+ * the 16-byte header and patches its record count. */
+int fdr_kmer_output_append(const char *path, int64_t n_records, const int64_t *name_off, const char *names,
+                           const int64_t *indptr, const int32_t *indices);
 
 /* ---- overlaps.tsv writer (host only: no context, no GPU) ---------------------------------------------
  * Replaces get_output_dataframe + DataFrame.to_csv(sep="\t", index=False) (fedrann/__main__.py:261-300,

@@ -32,6 +32,7 @@
 #include "../../fedrann_amd/csrc/projection_tables.inc"
 #include "../../fedrann_amd/csrc/csr_compact.inc"
 #include "../../fedrann_amd/csrc/kmer_output_loader.inc"
+#include "../../fedrann_amd/csrc/reads_parser.inc"
 #include "../../fedrann_amd/csrc/overlaps_writer.inc"
 
 template <typename T>
@@ -84,6 +85,74 @@ static int cmd_loader_range(const char *path, long long F, int threads, long lon
     printf("rc=0 R=%lld nnz=%lld sums=%llu,%llu,%llu,%llu\n", (long long)R, (long long)nnz,
            (unsigned long long)wsum(indptr), (unsigned long long)wsum(indices), (unsigned long long)wsum(name_off),
            (unsigned long long)wsum(names));
+    return 0;
+}
+
+// a FASTA / FASTQ file streamed in pieces of `chunk` bytes through fdr_reads_scan / fdr_reads_parse, every array
+// sized EXACTLY (an overrun is an ASan report); the records go back out through fdr_kmer_output_append with one
+// "index" per record (its sequence length), which exercises the writer under the sanitizers as well
+static int cmd_reads(const char *path, long long chunk, int ids_as_fasta, const char *out_path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return 1;
+    std::vector<uint8_t> buf;
+    size_t have = 0;
+    bool eof = false;
+    int is_fastq = -1;
+    long long n_rec = 0, n_bases = 0;
+    unsigned long long s_seq = 0, s_ids = 0;
+    {
+        FILE *o = fopen(out_path, "wb");
+        if (!o) return 1;
+        const unsigned char hdr[16] = {'K', 'M', 'E', 'R', 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        fwrite(hdr, 1, 16, o);
+        fclose(o);
+    }
+    while (!eof) {
+        std::vector<uint8_t> piece(have + (size_t)chunk);  // (a fresh, exactly sized buffer per piece)
+        if (have) memcpy(piece.data(), buf.data(), have);
+        const size_t got = fread(piece.data() + have, 1, (size_t)chunk, f);
+        piece.resize(have + got);
+        eof = got < (size_t)chunk;
+        if (is_fastq < 0) is_fastq = !piece.empty() && piece[0] == '@';
+        int64_t used = 0, R = 0, nb = 0;
+        int rc = fdr_reads_scan(piece.data(), (int64_t)piece.size(), is_fastq, ids_as_fasta, eof ? 1 : 0, &used, &R, &nb);
+        if (rc) {
+            printf("rc=%d err=%s\n", rc, g_err);
+            return 0;
+        }
+        std::vector<uint8_t> seqs((size_t)nb);
+        std::vector<int64_t> off((size_t)R + 1), span((size_t)(2 * R));
+        rc = fdr_reads_parse(piece.data(), used, is_fastq, ids_as_fasta, R, nb, seqs.data(), off.data(), span.data());
+        if (rc) {
+            printf("rc=%d err=%s\n", rc, g_err);
+            return 0;
+        }
+        std::vector<int64_t> name_off((size_t)R + 1, 0), indptr((size_t)R + 1, 0);
+        std::vector<char> names;
+        std::vector<int32_t> idx((size_t)R);
+        for (int64_t r = 0; r < R; ++r) {
+            for (int64_t i = span[(size_t)(2 * r)]; i < span[(size_t)(2 * r + 1)]; ++i) {
+                s_ids = s_ids * 1099511628211ull + piece[(size_t)i];
+                names.push_back((char)(piece[(size_t)i] < 32 || piece[(size_t)i] > 126 ? '?' : piece[(size_t)i]));
+            }
+            s_ids = s_ids * 1099511628211ull + 255;
+            name_off[(size_t)r + 1] = (int64_t)names.size();
+            idx[(size_t)r] = (int32_t)(off[(size_t)r + 1] - off[(size_t)r]);
+            indptr[(size_t)r + 1] = r + 1;
+        }
+        for (uint8_t c : seqs) s_seq = s_seq * 1099511628211ull + c;
+        rc = fdr_kmer_output_append(out_path, R, name_off.data(), names.data(), indptr.data(), idx.data());
+        if (rc) {
+            printf("rc=%d err=%s\n", rc, g_err);
+            return 0;
+        }
+        n_rec += R;
+        n_bases += nb;
+        buf.assign(piece.begin() + used, piece.end());
+        have = buf.size();
+    }
+    fclose(f);
+    printf("rc=0 R=%lld bases=%lld seq=%llu ids=%llu\n", n_rec, n_bases, s_seq, s_ids);
     return 0;
 }
 
@@ -227,6 +296,7 @@ int main(int argc, char **argv) {
     if (cmd == "loader-stale" && argc == 4) return cmd_loader(argv[2], atoll(argv[3]), 2, true);
     if (cmd == "loader-range" && argc == 8)
         return cmd_loader_range(argv[2], atoll(argv[3]), atoi(argv[4]), atoll(argv[5]), atoll(argv[6]), atoi(argv[7]));
+    if (cmd == "reads" && argc == 6) return cmd_reads(argv[2], atoll(argv[3]), atoi(argv[4]), argv[5]);
     if (cmd == "tables" && argc == 5) return cmd_tables((unsigned)atoi(argv[2]), atoll(argv[3]), atoi(argv[4]));
     if (cmd == "plan") return cmd_plan();
     if (cmd == "floats" && argc == 3) {  // host_san floats N: float32 bit patterns (one hex word per line on stdin) -> text

@@ -112,6 +112,46 @@ def test_ranged_loader_under_sanitizers_matches_library(san, tmp_path):
     assert int(_fields(san("loader-range", p, 2 * L, 1, 10, R + 1, 1))["rc"]) == -1
 
 
+def _fnv(chunks):
+    h = 0
+    for c in chunks:
+        for b in c:
+            h = (h * 1099511628211 + b) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fastq"])
+def test_reads_parser_and_appender_under_sanitizers(san, tmp_path, kind):
+    """fdr_reads_scan / fdr_reads_parse / fdr_kmer_output_append on a messy FASTA / FASTQ file streamed in pieces
+    of 1 byte to 1 MB with exactly sized arrays: no sanitizer report, and the records are those of the numpy
+    statement of the reader (names, sequences) whatever the piece size."""
+    from fedrann_amd import kmer_search as ks
+    from test_kmer_host import _mixed_fasta, _mixed_fastq
+    rng = np.random.default_rng(12)
+    raw = (_mixed_fasta if kind == "fasta" else _mixed_fastq)(rng, 200)
+    p = tmp_path / ("reads." + kind)
+    p.write_bytes(raw)
+    for flag in (0, 1):
+        ids, seqs, off = ks._parse_records(raw, kind == "fastq", bool(flag))
+        want_ids = _fnv(i + b"\xff" for i in ids)
+        want_seq = _fnv([seqs.tobytes()])
+        for chunk in (1, 7, 300, 1 << 20):
+            out = tmp_path / "out.bin"
+            f = _fields(san("reads", p, chunk, flag, out))
+            assert f["rc"] == "0" and int(f["R"]) == len(ids) and int(f["bases"]) == seqs.size
+            assert int(f["seq"]) == want_seq and int(f["ids"]) == want_ids
+            # the appended records: one index per record = its sequence length
+            blob = out.read_bytes()
+            pos, lens = 16, []
+            while pos < len(blob):
+                nb = struct.unpack_from("<H", blob, pos)[0]
+                cnt = struct.unpack_from("<I", blob, pos + 2 + nb)[0]
+                lens.append(struct.unpack_from("<Q", blob, pos + 6 + nb)[0])
+                assert cnt == 1
+                pos += 6 + nb + 8
+            assert lens == np.diff(off).tolist()
+
+
 def test_loader_errors_under_sanitizers_match_library(san, tmp_path):
     """Every malformed file of tests/test_host.py::test_native_output_bin_loader_errors: same return code
     from the sanitized build as from the library, and no out-of-bounds access on the way."""

@@ -85,6 +85,18 @@ def test_output_bin_writer_round_trip(tmp_path):
     assert names[0::2] == [x.decode() for x in ids] and strands[:2] == [0, 1]
     for r, want in enumerate(rows):
         assert ix2[ip2[2 * r]:ip2[2 * r + 1]].tolist() == want.tolist()
+    # the native appender (what the streaming kmer_searcher uses) writes the same bytes, in any grouping
+    from fedrann_amd import _lib
+    q = tmp_path / "appended.bin"
+    q.write_bytes(p.read_bytes()[:16])
+    for lo, hi in ((0, 0), (0, 70), (70, 71), (71, 200)):
+        _lib.kmer_output_append(str(q), ids[lo:hi], indptr[lo:hi + 1] - indptr[lo], indices[indptr[lo]:indptr[hi]])
+    assert q.read_bytes() == p.read_bytes()
+    size = q.stat().st_size
+    for bad in ([b"bad\xffid"], [b"x" * 70000], [b"tab\tid"]):
+        with pytest.raises(ValueError):
+            _lib.kmer_output_append(str(q), bad, [0, 0], [])
+    assert q.stat().st_size == size  # (nothing is written when a record is refused)
     with pytest.raises(ValueError):
         ks.write_output_bin(str(p), [b"bad\xffid"], [0, 0], [])
     ks.write_kmer_frequency_bin(str(tmp_path / "f.bin"), indices, F)
@@ -149,3 +161,60 @@ def test_streaming_reader_equals_whole_file_reader(tmp_path, kind, ids_as_fasta)
     empty = tmp_path / "empty.fa"
     empty.write_bytes(b"")
     assert list(ks.iter_sequence_blocks(str(empty))) == []
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fastq"])
+def test_native_reader_equals_numpy_statement_on_truncated_pieces(kind):
+    """fdr_reads_scan / fdr_reads_parse against the numpy statement of the rules (_complete_prefix +
+    _parse_records) on pieces cut at arbitrary bytes: inside headers, sequences, quality lines, with and without
+    the end-of-file flag (a FASTQ record missing its last lines at the end of the file keeps what is there)."""
+    from fedrann_amd import _lib
+    rng = np.random.default_rng(3)
+    raw = (_mixed_fasta if kind == "fasta" else _mixed_fastq)(rng, 120)
+    is_fastq = kind == "fastq"
+    cuts = sorted(set(rng.integers(0, len(raw), size=150).tolist() + [0, 1, 2, len(raw) - 1, len(raw)]))
+    for n in cuts:
+        piece = raw[:n]
+        buf = np.frombuffer(piece, dtype=np.uint8).copy() if n else np.zeros(1, dtype=np.uint8)
+        for eof in (False, True):
+            for flag in (False, True):
+                used, ids, seqs, off = _lib.reads_parse(buf, n, is_fastq, flag, eof)
+                want_used = ks._complete_prefix(piece, is_fastq, eof)
+                w_ids, w_seqs, w_off = ks._parse_records(piece[:want_used], is_fastq, flag)
+                assert used == want_used, (n, eof, flag)
+                assert ids == w_ids and np.array_equal(seqs, w_seqs) and np.array_equal(off, w_off), (n, eof, flag)
+
+
+@pytest.mark.parametrize("k", [5, 15, 31])
+def test_vectorised_library_files_equal_the_line_by_line_ones(k):
+    """run_kmer_searcher's library files and in-memory library: '>count' / k-mer lines built with array operations
+    equal the per-record text (counts of 1 to 17 digits), the reverse library equals what `seqkit seq -r -p` makes
+    of the forward one, and the codes handed to the search equal load_kmer_library of `cat fwd rev | grep -v '^>'`
+    (a palindromic k-mer keeps its forward slot only)."""
+    from fedrann_amd import count_kmers as ck
+    rng = np.random.default_rng(k)
+    codes = np.unique(rng.integers(0, 1 << min(2 * k, 62), size=5000).astype(np.uint64))
+    counts = rng.integers(1, 5000, size=codes.size).astype(np.uint64)
+    counts[:5] = [1, 9, 10, 99999, 12345678901234567]
+    kk = ck.codes_to_kmers(codes, k)
+    want = b"".join(b">%d\n" % c + row.tobytes() + b"\n" for c, row in zip(counts.tolist(), kk))
+    assert ck.kmer_library_text(codes, counts, k).tobytes() == want
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rc = ck.revcomp_codes(codes, k)
+    want_rev = b"".join(b">%d\n" % c + row.tobytes().translate(comp)[::-1] + b"\n" for c, row in zip(counts.tolist(), kk))
+    assert ck.kmer_library_text(rc, counts, k).tobytes() == want_rev
+    texts = [b"\n".join(l for l in t.split(b"\n") if not l.startswith(b">")) + b"\n" for t in (want, want_rev)]
+    assert np.array_equal(ks.load_kmer_library(texts, k), ks.unique_first(np.concatenate((codes, rc))))
+    assert ck.kmer_library_text(codes[:0], counts[:0], k).size == 0
+
+
+def test_library_of_palindromes_keeps_forward_slots():
+    from fedrann_amd import count_kmers as ck
+    k = 4
+    codes = np.array(sorted({0b00011011, 0b00000000, 0b11100100, 0b01101001}), dtype=np.uint64)  # ACGT is its own reverse complement
+    rc = ck.revcomp_codes(codes, k)
+    acgt = np.uint64(0b00011011)
+    assert rc[codes == acgt][0] == acgt
+    lib = ks.unique_first(np.concatenate((codes, rc)))
+    assert (lib == acgt).sum() == 1 and lib.size == np.unique(np.concatenate((codes, rc))).size
+    assert np.array_equal(lib[:codes.size], codes)  # (forward slots first, in their order)
