@@ -862,7 +862,8 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
 #endif
 
     if ((trc = timing_begin(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
-    hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st,
+    const int64_t mq = p.nseg * kp <= 64 ? 4 * MERGE_QPW : 4;  // queries per workgroup of knn_merge_keys_kernel
+    hipLaunchKernelGGL(knn_merge_keys_kernel, dim3((unsigned)((nq + mq - 1) / mq)), dim3(256), 0, st,
                        (const u64 *)d_partial, p.nseg, (int)nq, p.nq_pad, kp, d_cand);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(d_counter, 0, 16, st));
