@@ -293,7 +293,10 @@ def _rows_with_duplicate_classes(rng, n, d, n_unique):
 
 
 @pytest.mark.parametrize("n,d,k,n_unique", [(40_000, 128, 20, 5000), (30_000, 200, 50, 300),
-                                            (20_000, 128, 64, 400)])
+                                            (20_000, 128, 64, 400),
+                                            # (the expansion packs floor(64 / k) queries into a wave: 64, 21, 9, 1)
+                                            (20_000, 128, 1, 400), (20_000, 128, 3, 2000), (24_000, 128, 7, 6000),
+                                            (25_000, 128, 33, 3000)])
 def test_knn_duplicate_row_classes(ctx, oracle, n, d, k, n_unique):
     """Inputs dominated by duplicate rows: the class layer must return the same bits as the plain
     all-pairs search (members of a class in ascending index order, lists cut in the middle of a class)."""
