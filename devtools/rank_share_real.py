@@ -18,7 +18,7 @@ G = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 oracle.lib()
 ctx = _lib.Context(0)
-kw = dict(d=128, k=20, doubling=False) if cfg == 4 else dict(d=256, k=50, doubling=True, sample=128)
+kw = dict(d=128, k=20, doubling=False) if cfg == 4 else dict(d=256, k=50, doubling=True, sample=64)
 info = run_rank_share(ctx, oracle, R=R, ranks=G, reps=reps,
                       log=lambda *a: print("[config%d]" % cfg, *a, file=sys.stderr, flush=True), **kw)
 info["device"] = ctx.device_info()

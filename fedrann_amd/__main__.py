@@ -247,10 +247,11 @@ def run_fedrann_pipeline(*, output_dir, embedding_dimension, nndescent_n_trees,
     logger.info("Pipeline completed.")
 
 
-def doubled_names(name_off, name_buf):
-    """(name_off, names) of the R records -> the same for the 2R doubled rows (row 2r and 2r + 1 carry record r's
-    id), as fdr_overlaps_write takes them.  Ids that are not valid UTF-8 follow the reference's rule
-    (feature_extraction.py:125-128) through the str path."""
+def record_names(name_off, name_buf):
+    """(name_off, names) of the R records as fdr_overlaps_write takes them in its doubled-rows mode (strands=None: row
+    t carries record t >> 1's id -- no id is materialised twice, let alone gathered byte by byte).  Valid UTF-8 ids
+    pass through untouched; ids that are not follow the reference's rule (feature_extraction.py:125-128) through the
+    str path."""
     from . import _lib
     from .feature_extraction import _decode_names
     raw = name_buf.tobytes()
@@ -258,20 +259,16 @@ def doubled_names(name_off, name_buf):
         try:
             raw.decode("utf-8")
         except UnicodeDecodeError:
-            return _lib.pack_names([n for n in _decode_names(name_off, name_buf) for _ in (0, 1)])
-    lens = np.diff(name_off)
-    off2 = np.zeros(2 * lens.size + 1, dtype=np.int64)
-    np.cumsum(np.repeat(lens, 2), out=off2[1:])
-    src = np.repeat(name_off[:-1], 2)  # first byte of every doubled row's id in name_buf
-    pos = np.arange(int(off2[-1]), dtype=np.int64) - np.repeat(off2[:-1], np.repeat(lens, 2)) + np.repeat(src, np.repeat(lens, 2))
-    return off2, np.ascontiguousarray(name_buf[pos])
+            return _lib.pack_names(_decode_names(name_off, name_buf))
+    return name_off, name_buf
 
 
 def load_rank_inputs(args, output_dir, rank, world):
     """What ONE rank of `--devices` needs on the host: the projection matrix, ITS row block of the read x feature
     CSR (1 / world of the matrix: the ranged native loader for output.bin; a feature_matrix.npz is inflated whole
     and sliced, scipy's format has no random access) and the names / strands of all rows for the writer.
-    Returns (n_rows, lo, hi, indptr, indices, n_features, P, name_off, names, strands)."""
+    Returns (n_rows, lo, hi, indptr, indices, n_features, P, name_off, names, strands); strands is None when
+    name_off / names describe the R records of a doubled matrix (fdr_overlaps_write's doubled-rows mode)."""
     from . import _lib
     from .distributed import local_csr, shard_rows
     if args.kmer_searcher_output:
@@ -279,11 +276,11 @@ def load_rank_inputs(args, output_dir, rank, world):
         n_features = 2 * int(read_kmer_counts(args.kmer_library).size)  # (count_kmers.py:148)
         P, n_features = get_precompute_matrix(n_components=args.embedding_dimension, counter_file=args.kmer_library,
                                               n_features=n_features)
-        R, _, _, _, _ = _lib.kmer_output_load_range(args.kmer_searcher_output, n_features, 0, 0, with_names=False)
-        n = 2 * R
-        _, blocks = shard_rows(n, world)
-        lo, hi = blocks[rank]
         try:
+            R = _lib.kmer_output_records(args.kmer_searcher_output)  # (the header's count: no record is walked for it)
+            n = 2 * R
+            _, blocks = shard_rows(n, world)
+            lo, hi = blocks[rank]
             _, ip, ix, name_off, name_buf = _lib.kmer_output_load_range(
                 args.kmer_searcher_output, n_features, lo // 2, hi // 2,
                 n_threads=global_variables.threads if global_variables.threads > 1 else 0)
@@ -291,8 +288,8 @@ def load_rank_inputs(args, output_dir, rank, world):
             if "output.bin:" in str(e):  # format errors keep the reference's exception type
                 raise ValueError(str(e).split("output.bin:", 1)[1].strip()) from None
             raise
-        name_off, names = doubled_names(name_off, name_buf)
-        strands = np.tile(np.array([0, 1], dtype=np.uint8), R)
+        name_off, names = record_names(name_off, name_buf)
+        strands = None  # (fdr_overlaps_write's doubled-rows mode: row t = record t >> 1 on strand t & 1)
         if args.save_feature_matrix and rank == 0:  # (the whole matrix, once)
             from .feature_extraction import build_feature_csr
             fip, fix, _, _ = build_feature_csr(args.kmer_searcher_output, n_features)
@@ -330,13 +327,17 @@ def run_rank_worker(args, output_dir, temp_dir):
     torch.cuda.set_device(device)
     # rendezvous through a file in temp/ (no port to lose to another process); the host stages between two
     # collectives (loading a rank's rows of a 10 M-read matrix, writing its part of overlaps.tsv) may take long
+    # (FEDRANN_COLLECTIVE_TIMEOUT_S: how long a rank waits inside one collective, default 2 h -- the only long host stage
+    # between two collectives is the load below, and a barrier right after it takes that wait; a rank that hangs without
+    # dying no longer holds its siblings for half a day)
     kw = dict(init_method="file://" + os.environ["FEDRANN_RENDEZVOUS"], rank=rank, world_size=world,
-              timeout=datetime.timedelta(hours=12))
+              timeout=datetime.timedelta(seconds=float(os.environ.get("FEDRANN_COLLECTIVE_TIMEOUT_S", "7200"))))
     if args.dist_backend == "nccl":
         dist.init_process_group("nccl", device_id=device, **kw)
     else:
         dist.init_process_group("gloo", **kw)
     n, lo, hi, ip, ix, n_features, P, name_off, names, strands = load_rank_inputs(args, output_dir, rank, world)
+    dist.barrier()  # every rank has its rows: what follows is GPU work and short collectives
     k = args.nndescent_n_neighbors
     ctx = _lib.Context(device.index)
     Pc = _projection_csr(P)
@@ -395,27 +396,39 @@ def launch_rank_workers(argv, args, devices, output_dir, temp_dir, keep_intermed
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(rank),
                    FEDRANN_DEVICE=str(dev), FEDRANN_RENDEZVOUS=rendezvous)
         procs.append(subprocess.Popen([sys.executable, "-m", "fedrann_amd"] + argv + ["--rank-worker"], env=env))
-    # poll all ranks: the first failure ends the others (they would sit in a collective until its timeout)
+    # poll all ranks: the first failure ends the others (they would sit in a collective until its timeout); whatever ends
+    # the parent -- KeyboardInterrupt, SIGTERM turned into SystemExit, an error here -- ends the ranks and removes the
+    # rendezvous file too
     codes = [None] * len(procs)
-    while any(c is None for c in codes):
+
+    def end_ranks():
+        for i, p in enumerate(procs):
+            if codes[i] is None and p.poll() is None:
+                p.terminate()
         for i, p in enumerate(procs):
             if codes[i] is None:
-                codes[i] = p.poll()
-        if any(c not in (None, 0) for c in codes):
+                try:
+                    codes[i] = p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    codes[i] = p.wait()
+
+    import signal
+    old_term = signal.signal(signal.SIGTERM, lambda *_: sys.exit(143))
+    try:
+        while any(c is None for c in codes):
             for i, p in enumerate(procs):
                 if codes[i] is None:
-                    p.terminate()
-            for i, p in enumerate(procs):
-                if codes[i] is None:
-                    try:
-                        codes[i] = p.wait(timeout=10)
-                    except subprocess.TimeoutExpired:
-                        p.kill()
-                        codes[i] = p.wait()
-            break
-        time.sleep(0.05)
-    if os.path.exists(rendezvous):
-        os.remove(rendezvous)
+                    codes[i] = p.poll()
+            if any(c not in (None, 0) for c in codes):
+                end_ranks()
+                break
+            time.sleep(0.05)
+    finally:
+        end_ranks()
+        signal.signal(signal.SIGTERM, old_term)
+        if os.path.exists(rendezvous):
+            os.remove(rendezvous)
     if any(codes):
         raise SystemExit("rank worker(s) failed: exit codes %s" % codes)
     out = join(output_dir, "overlaps.tsv")

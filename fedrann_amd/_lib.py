@@ -21,12 +21,14 @@ SYMBOLS = (
     "fdr_overlaps_write", "fdr_last_prefilter_launches", "fdr_knn_classes_dev", "fdr_knn_unique_dev",
     "fdr_knn_expand_dev", "fdr_kmer_output_scan_range", "fdr_kmer_output_load_range",
     "fdr_kmer_count_begin", "fdr_kmer_count_add", "fdr_kmer_count_finish", "fdr_reads_scan", "fdr_reads_parse",
-    "fdr_kmer_output_append",
+    "fdr_kmer_output_append", "fdr_last_query_paths",
 )
 FDR_MAX_K = 128
 KERNELS = ("embed_csr", "normalize_rows", "knn_tile", "knn_merge", "knn_prefilter", "knn_rerank",
            "knn_dedup", "kmer_search", "kmer_compact")
 FDR_MAX_DIM = 2048
+# fdr_last_query_paths codes (include/fedrann_hip.h: FDR_PATH_*)
+PATH_CERTIFIED, PATH_RANGE, PATH_EXACT, PATH_ZERO, PATH_RANGE_OVERFLOW, PATH_GENERIC, PATH_CLASS_MEMBER = 1, 2, 3, 4, 5, 6, 0x80
 
 
 class FedrannHipError(RuntimeError):
@@ -87,6 +89,7 @@ def load_library():
     L.fdr_knn_unique_dev.argtypes = [vp, i64, i64, vp, vp, vp]
     L.fdr_knn_expand_dev.argtypes = [vp, i64, i64, i64, vp, vp, i64, vp, vp, vp]
     L.fdr_last_uncertified.argtypes = [vp]
+    L.fdr_last_query_paths.argtypes = [vp, vp, i64]
     L.fdr_set_knn_mode.argtypes = [vp, ctypes.c_int]
     L.fdr_set_dedup_mode.argtypes = [vp, ctypes.c_int]
     L.fdr_last_unique.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
@@ -154,6 +157,22 @@ def kmer_output_load(path, n_features, n_threads=0):
     return indptr, indices, name_off, names
 
 
+def kmer_output_records(path):
+    """Record count of an output.bin from its 16-byte header ('<4sB3sQ', feature_extraction.py:110-119); the
+    reference's ValueError for a bad magic / version.  No record is read."""
+    import struct
+    with open(path, "rb") as f:
+        head = f.read(16)
+    if len(head) < 16:
+        raise ValueError("incomplete file header")
+    magic, version, _, total = struct.unpack("<4sB3sQ", head)
+    if magic != b"KMER":
+        raise ValueError("invalid file format (bad magic)")
+    if version != 1:
+        raise ValueError("unsupported version: %d" % version)
+    return int(total)
+
+
 def kmer_output_load_range(path, n_features, rec_lo, rec_hi, n_threads=0, with_names=True):
     """Rows of the records [rec_lo, rec_hi) of output.bin (rec_hi = None: to the end) -- a rank's block of a
     row-sharded run -- as (n_records of the file, indptr int64 [2 (hi - lo) + 1] rebased to 0, indices int32,
@@ -161,11 +180,9 @@ def kmer_output_load_range(path, n_features, rec_lo, rec_hi, n_threads=0, with_n
     L = load_library()
     bpath = os.fsencode(path)
     R, nnz, nb = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-    rc = L.fdr_kmer_output_scan(bpath, ctypes.byref(R), ctypes.byref(nnz), ctypes.byref(nb))
-    if rc != 0:
-        raise FedrannHipError("fdr_kmer_output_scan failed (%d): %s" % (rc, L.fdr_last_error().decode()))
-    lo = max(0, min(int(rec_lo), R.value))
-    hi = R.value if rec_hi is None else max(lo, min(int(rec_hi), R.value))
+    total = kmer_output_records(path)  # (the header's count clamps the range; one walk over the records below, not two)
+    lo = max(0, min(int(rec_lo), total))
+    hi = total if rec_hi is None else max(lo, min(int(rec_hi), total))
     rc = L.fdr_kmer_output_scan_range(bpath, lo, hi, ctypes.byref(R), ctypes.byref(nnz), ctypes.byref(nb))
     if rc != 0:
         raise FedrannHipError("fdr_kmer_output_scan_range failed (%d): %s" % (rc, L.fdr_last_error().decode()))
@@ -235,7 +252,8 @@ def pack_names(read_names):
 
 def overlaps_write(path, idx, dist, name_off, names, strands, row0=0, append=False, header=True, n_threads=0):
     """overlaps.tsv rows of neighbour-graph rows row0 .. row0 + idx.shape[0] (host only, no GPU); returns the
-    number of data lines.  See fdr_overlaps_write."""
+    number of data lines.  strands=None: name_off / names describe the RECORDS of a fwd / rev doubled matrix (row t =
+    record t >> 1, strand t & 1).  See fdr_overlaps_write."""
     L = load_library()
     idx = _as(idx, np.int32, "idx")
     dist = _as(dist, np.float32, "dist")
@@ -243,14 +261,18 @@ def overlaps_write(path, idx, dist, name_off, names, strands, row0=0, append=Fal
         raise ValueError("idx and dist must be [rows, k] arrays of the same shape")
     name_off = _as(name_off, np.int64, "name_off")
     names = np.ascontiguousarray(names, dtype=np.uint8)
-    strands = np.ascontiguousarray(strands, dtype=np.uint8)
-    n_total = name_off.size - 1
-    if strands.size != n_total:
-        raise ValueError("strands must have one entry per row")
+    if strands is None:  # doubled rows: one name per RECORD, row t = record t >> 1 on strand t & 1
+        n_total = 2 * (name_off.size - 1)
+    else:
+        strands = np.ascontiguousarray(strands, dtype=np.uint8)
+        n_total = name_off.size - 1
+        if strands.size != n_total:
+            raise ValueError("strands must have one entry per row")
     lines = ctypes.c_int64()
     rc = L.fdr_overlaps_write(os.fsencode(path), 1 if append else 0, 1 if header else 0, n_total, int(row0),
                               idx.shape[0], idx.shape[1], _ptr(idx), _ptr(dist), _ptr(name_off),
-                              names.ctypes.data if names.size else None, _ptr(strands), int(n_threads),
+                              names.ctypes.data if names.size else None, _ptr(strands) if strands is not None else None,
+                              int(n_threads),
                               ctypes.byref(lines))
     if rc != 0:
         raise FedrannHipError("fdr_overlaps_write failed (%d): %s" % (rc, L.fdr_last_error().decode()))
@@ -392,6 +414,13 @@ class Context:
     def last_uncertified(self):
         """Prefilter mode: query rows of the last k-NN call that were searched by the exact kernel."""
         return int(self._L.fdr_last_uncertified(self._h))
+
+    def last_query_paths(self, n_queries):
+        """uint8 [n_queries]: which way every query row of the last k-NN call took to its result (PATH_* codes, bit 7 =
+        member of a duplicate-row class of several rows): fdr_last_query_paths.  Diagnostics; the tests' strata."""
+        out = np.empty(int(n_queries), dtype=np.uint8)
+        self._check(self._L.fdr_last_query_paths(self._h, _ptr(out), int(n_queries)), "fdr_last_query_paths")
+        return out
 
     def timing(self, enable):
         self._check(self._L.fdr_timing(self._h, 1 if enable else 0), "fdr_timing")

@@ -177,8 +177,10 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restr
 #include "knn_plan.inc"           // shapes, LDS budgets, target segments (plain C++)
 #include "projection_tables.inc"  // the embed kernel's lookup tables (plain C++)
 #include "csr_compact.inc"        // dead-feature filter (plain C++)
+#include "host_upload.inc"        // host CSR -> device in chunks: raw over PCIe and compacted on the host at once
 #include "knn_exact.inc"      // K3 / K4: fp32 MFMA tile kernel with LDS top-k lists, merge
 #include "knn_prefilter.inc"  // P1 / P2: fp16 MFMA candidate pass, merges, certificate + re-rank, range pass
+#include "knn_prefilter_pp.inc"  // P1 for the 256-register shapes: the two waves of a SIMD take turns at the matrix pipe
 #include "knn_order.inc"      // P1: scan order by chunk mask (sort keys, ordered fp16 copy)
 #include "dedup_classes.inc"  // duplicate-row classes: hash, tables, gathers, expansion
 #include "knn_generic.inc"    // d > 512 or k > 64: every pair on the vector ALU
@@ -224,6 +226,9 @@ struct fdr_ctx {
     std::vector<uint32_t> h_bits;  // host copy of ftab's bitmap words
     // scratch for the host-pointer API
     DevBuf a_indptr, a_indices, E, Ehat, zero, idx, dist, ws;
+    DevBuf c_indptr, c_indices;             // ... the chunks the host compacted (upload_embed_pipelined)
+    hup::PinnedBuf stage_ids, stage_ptr;    // ... their pinned staging
+    hipEvent_t up_ev[2] = {nullptr, nullptr};  // ... the two raw chunks in flight
     // k-mer search (kmer_search.inc)
     DevBuf ks_seq, ks_off, ks_codes, ks_keys, ks_vals, ks_bloom, ks_counter, ks_pairs, ks_pairs2, ks_flag, ks_pos,
         ks_idx, ks_rows, ks_indptr, ks_tmp, kc_counts;
@@ -240,6 +245,13 @@ struct fdr_ctx {
     int last_flagged = 0;  // prefilter mode: queries of the last call that took the exact path
     int last_unique_targets = 0, last_unique_queries = 0;  // duplicate-row classes of the last call
     int last_pass_launches = 0, last_pass_queues = 0;      // prefilter pass of the last call
+    // fdr_last_query_paths: the last call's per-query path codes (in that call's workspace), or one code for all rows
+    struct {
+        const uint8_t *dev = nullptr;
+        int64_t n = 0;  // 0: nothing recorded
+        uint8_t all = 0;
+        hipStream_t stream = nullptr;
+    } paths;
     // duplicate-row classes built by fdr_knn_classes_dev for the calls that follow it (fdr_knn_unique_dev /
     // fdr_knn_expand_dev): the tables live in the caller's workspace
     struct {
@@ -326,6 +338,12 @@ FDR_EXPORT int fdr_destroy(fdr_ctx *ctx) {
                       &ctx->ks_idx, &ctx->ks_rows, &ctx->ks_indptr, &ctx->ks_tmp, &ctx->kc_counts,
                       &ctx->kc_a0, &ctx->kc_a1, &ctx->kc_c0, &ctx->kc_c1, &ctx->kc_mk, &ctx->kc_mv, &ctx->kc_rc};
     for (DevBuf *b : bufs) b->release();
+    ctx->c_indptr.release();
+    ctx->c_indices.release();
+    ctx->stage_ids.release();
+    ctx->stage_ptr.release();
+    for (hipEvent_t e : ctx->up_ev)
+        if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < FDR_NUM_KERNELS; ++i)
         for (hipEvent_t e : ctx->ev_pool[i]) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
@@ -348,6 +366,22 @@ FDR_EXPORT int fdr_device_info(fdr_ctx *ctx, char *buf, int buflen) {
 }
 
 FDR_EXPORT int fdr_last_uncertified(fdr_ctx *ctx) { return ctx ? ctx->last_flagged : 0; }
+
+FDR_EXPORT int fdr_last_query_paths(fdr_ctx *ctx, uint8_t *paths, int64_t n_queries) {
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (!paths || n_queries <= 0) return fail(FDR_E_ARG, "last_query_paths: bad argument");
+    if (ctx->paths.n != n_queries)
+        return fail(FDR_E_STATE, "last_query_paths: the last k-NN call recorded codes for %lld query rows, not %lld",
+                    (long long)ctx->paths.n, (long long)n_queries);
+    if (!ctx->paths.dev) {
+        memset(paths, ctx->paths.all, (size_t)n_queries);
+        return FDR_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(paths, ctx->paths.dev, (size_t)n_queries, hipMemcpyDeviceToHost, ctx->paths.stream));
+    HIP_TRY(hipStreamSynchronize(ctx->paths.stream));
+    return FDR_OK;
+}
 
 FDR_EXPORT int fdr_last_unique(fdr_ctx *ctx, int *unique_targets, int *unique_queries) {
     if (!ctx || !unique_targets || !unique_queries) return fail(FDR_E_ARG, "bad argument");
@@ -535,6 +569,7 @@ struct PrefilterLayout {
     size_t knn_bytes;  // region shared (in stream order) by the prefilter pass and the exact passes
     size_t off_ht, off_hq, off_cand, off_counter, off_flagged, off_qc, off_qzc, off_idxc, off_distc;
     size_t off_rlist, off_theta, off_hqc, off_thetac, off_cnt, off_rcand, total;  // range pass
+    size_t off_path;  // per-query path codes (fdr_last_query_paths)
     int rchunk;
     int ordered;  // ordered scan possible: sort keys, order tables, ordered fp16 copies
     size_t off_okeys, off_okeys_s, off_ovals, off_perm_t, off_perm_q, off_ho_t, off_ho_q, off_otmp, otmp_bytes;
@@ -573,6 +608,7 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.off_thetac = o;   o += align256((size_t)L.rchunk * 4);
     L.off_cnt = o;      o += align256((size_t)L.rchunk * 4);
     L.off_rcand = o;    o += align256((size_t)L.rchunk * RANGE_CAP * 4);
+    L.off_path = o;     o += align256((size_t)nq);
     L.ordered = pp.cohort > 0 || dev_knobs().ordered != 0;  // (the sizes at which the pass runs in synchronised rounds)
     L.off_okeys = L.off_okeys_s = L.off_ovals = L.off_perm_t = L.off_perm_q = L.off_ho_t = L.off_ho_q = 0;
     L.off_otmp = L.otmp_bytes = 0;
@@ -693,6 +729,105 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
     return timing_end(ctx, FDR_KERNEL_KNN_MERGE, st);
 }
 
+// Development builds may compile a subset of the prefilter pass's shapes (-DFDR_SHAPE_MASK=<bits of the FDR_SHAPE_CASE
+// numbers below>, -DFDR_LH_MASK=<16 | 32>): the full set is ten minutes of hipcc.  The release library compiles all.
+#ifndef FDR_SHAPE_MASK
+#define FDR_SHAPE_MASK 0x7fff
+#endif
+#ifndef FDR_LH_MASK
+#define FDR_LH_MASK 48
+#endif
+#define FDR_SEL_1(...) __VA_ARGS__
+#define FDR_SEL_0(...) return fail(FDR_E_STATE, "this development build was compiled without the kernel shape this call needs")
+#define FDR_CAT2(a, b) a##b
+#define FDR_CAT(a, b) FDR_CAT2(a, b)
+#if (FDR_SHAPE_MASK >> 0) & 1
+#define FDR_SHAPE_ON_0 1
+#else
+#define FDR_SHAPE_ON_0 0
+#endif
+#if (FDR_SHAPE_MASK >> 1) & 1
+#define FDR_SHAPE_ON_1 1
+#else
+#define FDR_SHAPE_ON_1 0
+#endif
+#if (FDR_SHAPE_MASK >> 2) & 1
+#define FDR_SHAPE_ON_2 1
+#else
+#define FDR_SHAPE_ON_2 0
+#endif
+#if (FDR_SHAPE_MASK >> 3) & 1
+#define FDR_SHAPE_ON_3 1
+#else
+#define FDR_SHAPE_ON_3 0
+#endif
+#if (FDR_SHAPE_MASK >> 4) & 1
+#define FDR_SHAPE_ON_4 1
+#else
+#define FDR_SHAPE_ON_4 0
+#endif
+#if (FDR_SHAPE_MASK >> 5) & 1
+#define FDR_SHAPE_ON_5 1
+#else
+#define FDR_SHAPE_ON_5 0
+#endif
+#if (FDR_SHAPE_MASK >> 6) & 1
+#define FDR_SHAPE_ON_6 1
+#else
+#define FDR_SHAPE_ON_6 0
+#endif
+#if (FDR_SHAPE_MASK >> 7) & 1
+#define FDR_SHAPE_ON_7 1
+#else
+#define FDR_SHAPE_ON_7 0
+#endif
+#if (FDR_SHAPE_MASK >> 8) & 1
+#define FDR_SHAPE_ON_8 1
+#else
+#define FDR_SHAPE_ON_8 0
+#endif
+#if (FDR_SHAPE_MASK >> 9) & 1
+#define FDR_SHAPE_ON_9 1
+#else
+#define FDR_SHAPE_ON_9 0
+#endif
+#if (FDR_SHAPE_MASK >> 10) & 1
+#define FDR_SHAPE_ON_10 1
+#else
+#define FDR_SHAPE_ON_10 0
+#endif
+#if (FDR_SHAPE_MASK >> 11) & 1
+#define FDR_SHAPE_ON_11 1
+#else
+#define FDR_SHAPE_ON_11 0
+#endif
+#if (FDR_SHAPE_MASK >> 12) & 1
+#define FDR_SHAPE_ON_12 1
+#else
+#define FDR_SHAPE_ON_12 0
+#endif
+#if (FDR_SHAPE_MASK >> 13) & 1
+#define FDR_SHAPE_ON_13 1
+#else
+#define FDR_SHAPE_ON_13 0
+#endif
+#if (FDR_SHAPE_MASK >> 14) & 1
+#define FDR_SHAPE_ON_14 1
+#else
+#define FDR_SHAPE_ON_14 0
+#endif
+#if FDR_LH_MASK & 16
+#define FDR_LH_ON_16 1
+#else
+#define FDR_LH_ON_16 0
+#endif
+#if FDR_LH_MASK & 32
+#define FDR_LH_ON_32 1
+#else
+#define FDR_LH_ON_32 0
+#endif
+#define FDR_SHAPE_CASE(n, ...) FDR_CAT(FDR_SEL_, FDR_SHAPE_ON_##n)(__VA_ARGS__)
+#define FDR_LH_CASE(n, ...) FDR_CAT(FDR_SEL_, FDR_LH_ON_##n)(__VA_ARGS__)
 // ---- prefilter mode: fp16 pass -> certificate + exact re-rank -> exact pass for the rest -------
 static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero, int64_t nq,
                                 const float *d_That, const uint8_t *d_tzero, int64_t nt, int64_t t_base,
@@ -714,6 +849,10 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     int32_t *d_idxc = reinterpret_cast<int32_t *>(ws + L.off_idxc);
     float *d_distc = reinterpret_cast<float *>(ws + L.off_distc);
     const int kp = L.kp;
+    uint8_t *d_path = reinterpret_cast<uint8_t *>(ws + L.off_path);
+    ctx->paths.dev = d_path;
+    ctx->paths.n = nq;
+    ctx->paths.stream = st;
 
     const int dp = fdr_padded_dim(d);
     const int pshape = prefilter_shape(dp, kp, nq, ctx->num_cus);
@@ -818,24 +957,36 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     FDR_LAUNCH_PRE3((knn_prefilter_kernel<DP_, NQ_, NW_, WPS_, U_, LH_>), 64 * NW_)
 #define FDR_LAUNCH_PRE(DP_, NQ_, NW_, WPS_, U_)                                                         \
     do {                                                                                                \
-        if (kp <= 32) FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 16);                                     \
-        else FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 32);                                              \
+        if (kp <= 32) FDR_LH_CASE(16, FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 16));                    \
+        else FDR_LH_CASE(32, FDR_LAUNCH_PRE2(DP_, NQ_, NW_, WPS_, U_, 32));                             \
     } while (0)
+        // (FDR_SHAPE_CASE: a development build may compile a subset of the shapes, -DFDR_SHAPE_MASK=bits: 10 minutes of hipcc otherwise)
         if (dp == 128 && kp <= 32) {
             // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
             // <= 128 VGPRs)
-            if (sh.nw == 8) FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512);
-            else FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256);
-        } else if (dp == 128) FDR_LAUNCH_PRE(128, 1, 4, 4, 2);
-        else if (dp == 256 && sh.tps == 16 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 2, 8);
-        else if (dp == 256 && sh.tps == 8 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 2, 4);
-        else if (dp == 512 && sh.tps == 8 && sh.nw == 8) FDR_LAUNCH_PRE(512, 1, 8, 2, 4);
-        else if (dp == 256 && sh.tps == 8) FDR_LAUNCH_PRE(256, 1, 4, 2, 4);
-        else if (dp == 512 && sh.tps == 8) FDR_LAUNCH_PRE(512, 1, 4, 2, 4);
-        else if (dp == 256 && sh.wps == 2 && sh.nw == 8) FDR_LAUNCH_PRE(256, 1, 8, 2, 2);
-        else if (dp == 256 && sh.wps == 2) FDR_LAUNCH_PRE(256, 1, 4, 2, 2);
-        else if (dp == 256) FDR_LAUNCH_PRE(256, 1, 4, 3, 2);
-        else FDR_LAUNCH_PRE(512, 1, 4, 2, 2);
+            if (sh.nw == 8) FDR_SHAPE_CASE(0, FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512));
+            else FDR_SHAPE_CASE(1, FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256));
+        } else if (dp == 128) FDR_SHAPE_CASE(2, FDR_LAUNCH_PRE(128, 1, 4, 4, 2));
+        else if (sh.tps == 16 && sh.nw == 8 && sh.wps == 2 && !(dp == 256 && dev_knobs().pp == 0)) {
+            // the ping-pong kernel (knn_prefilter_pp.inc)
+#define FDR_LAUNCH_PP(DP_)                                                                               \
+    do {                                                                                                 \
+        if (kp <= 32) FDR_LH_CASE(16, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<DP_, 8, 16>), 512));     \
+        else FDR_LH_CASE(32, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<DP_, 8, 32>), 512));              \
+    } while (0)
+            if (dp == 128) FDR_SHAPE_CASE(12, FDR_LAUNCH_PP(128));
+            else if (dp == 256) FDR_SHAPE_CASE(3, FDR_LAUNCH_PP(256));
+            else FDR_SHAPE_CASE(13, FDR_LAUNCH_PP(512));
+#undef FDR_LAUNCH_PP
+        } else if (dp == 256 && sh.tps == 16 && sh.nw == 8) FDR_SHAPE_CASE(14, FDR_LAUNCH_PRE(256, 1, 8, 2, 8));
+        else if (dp == 256 && sh.tps == 8 && sh.nw == 8) FDR_SHAPE_CASE(4, FDR_LAUNCH_PRE(256, 1, 8, 2, 4));
+        else if (dp == 512 && sh.tps == 8 && sh.nw == 8) FDR_SHAPE_CASE(5, FDR_LAUNCH_PRE(512, 1, 8, 2, 4));
+        else if (dp == 256 && sh.tps == 8) FDR_SHAPE_CASE(6, FDR_LAUNCH_PRE(256, 1, 4, 2, 4));
+        else if (dp == 512 && sh.tps == 8) FDR_SHAPE_CASE(7, FDR_LAUNCH_PRE(512, 1, 4, 2, 4));
+        else if (dp == 256 && sh.wps == 2 && sh.nw == 8) FDR_SHAPE_CASE(8, FDR_LAUNCH_PRE(256, 1, 8, 2, 2));
+        else if (dp == 256 && sh.wps == 2) FDR_SHAPE_CASE(9, FDR_LAUNCH_PRE(256, 1, 4, 2, 2));
+        else if (dp == 256) FDR_SHAPE_CASE(10, FDR_LAUNCH_PRE(256, 1, 4, 3, 2));
+        else FDR_SHAPE_CASE(11, FDR_LAUNCH_PRE(512, 1, 4, 2, 2));
 #undef FDR_LAUNCH_PRE3
 #undef FDR_LAUNCH_PRE2
 #undef FDR_LAUNCH_PRE
@@ -849,6 +1000,22 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     ctx->last_pass_queues = nqueues;
     if ((lrc = join())) return lrc;  // the merge below (on `st`) needs the other queues' launches too
     if (nqueues > 1 && (trc = timing_end(ctx, FDR_KERNEL_KNN_PREFILTER, st))) return trc;
+#ifdef FDR_STAMPS
+    {
+        unsigned long long c[16][8];
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int q = 1; q < nqueues; ++q) HIP_TRY(hipStreamSynchronize(qs[q]));
+        HIP_TRY(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_stamps), sizeof(c)));
+        for (int w = 0; w < sh.nw; ++w) {
+            const double st_n = (double)std::max<unsigned long long>(1, c[w][5]);
+            fprintf(stderr, "[fdr stamps] wave %d: stages %llu  per stage (s_memtime ticks): dma-issue %.0f  mfma+score %.0f  "
+                            "share %.0f  vmcnt(0) %.0f  barrier %.0f\n", w, c[w][5], c[w][0] / st_n, c[w][1] / st_n, c[w][2] / st_n,
+                    c[w][3] / st_n, c[w][4] / st_n);
+        }
+        unsigned long long z[16][8] = {};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
+    }
+#endif
 #ifdef FDR_DEBUG_COUNTERS
     if (pdbg & 2) {
         unsigned long long c[8];
@@ -874,7 +1041,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                                 hipFuncAttributeMaxDynamicSharedMemorySize, RERANK_LDS_BYTES));
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), RERANK_LDS_BYTES, st,
                        (const u64 *)d_cand, kp, k, d_Qhat, d_qzero, d_That, (int)nq, dp, (int)t_base, margin,
-                       d_idx, d_dist, d_counter, d_flagged, d_rlist, d_theta);
+                       d_idx, d_dist, d_counter, d_flagged, d_rlist, d_theta, d_path);
     {   // all-zero queries share one closed-form answer (their number is only known on the device yet)
         int *d_zidx = d_counter + 64;
         float *d_zdist = reinterpret_cast<float *>(d_counter + 128);
@@ -925,7 +1092,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(knn_rerank_long_kernel, dim3((unsigned)((c + 3) / 4)), dim3(256), 0, st,
                                (const int *)(d_rlist + first), c, (const int *)d_cnt, (const int *)d_rcand, k,
-                               d_Qhat, d_That, dp, (int)t_base, d_idx, d_dist, d_counter, d_flagged);
+                               d_Qhat, d_That, dp, (int)t_base, d_idx, d_dist, d_counter, d_flagged, d_path);
             HIP_TRY(hipGetLastError());
         }
         if ((trc = timing_end(ctx, FDR_KERNEL_KNN_RERANK, st))) return trc;
@@ -969,6 +1136,9 @@ static int launch_knn_mode(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_q
                                     d_dist, d_ws, ws_bytes, st);
     ctx->last_flagged = 0;  // (exact mode certifies nothing)
     ctx->last_pass_launches = ctx->last_pass_queues = 0;
+    ctx->paths.dev = nullptr;
+    ctx->paths.n = nq;
+    ctx->paths.all = FDR_PATH_EXACT;
     return launch_knn_exact(ctx, d_Qhat, d_qzero, nq, d_That, d_tzero, nt, t_base, d, k, d_idx, d_dist,
                             d_ws, ws_bytes, st);
 }
@@ -978,7 +1148,7 @@ struct DedupLayout {
     size_t inner_bytes;  // workspace of the inner k-NN call (sized for the un-deduplicated problem)
     size_t off_hash, off_hash_s, off_idx, off_idx_s, off_flag, off_cid, off_cls, off_cstart, off_isrep,
         off_upos, off_uofc, off_cofu, off_uqflag, off_uqpos, off_U, off_uzero, off_Uq, off_uqz, off_idxu,
-        off_distu, off_tmp, tmp_bytes, total;
+        off_distu, off_rowpath, off_tmp, tmp_bytes, total;
 };
 
 #define FDR_DEDUP_PROBE_BELOW (1 << 18)
@@ -1015,6 +1185,7 @@ static DedupLayout dedup_layout(const fdr_ctx *ctx, int64_t nq, int64_t nt, int 
     L.off_uqz = take((size_t)nq);
     L.off_idxu = take((size_t)nq * k * 4);
     L.off_distu = take((size_t)nq * k * 4);
+    L.off_rowpath = take((size_t)nq);  // path codes of the original rows (fdr_last_query_paths)
     size_t t_sort = 0, t_scan = 0;
     (void)rocprim::radix_sort_pairs(nullptr, t_sort, (u64 *)nullptr, (u64 *)nullptr, (int *)nullptr,
                                     (int *)nullptr, (size_t)nt, 0, 64, (hipStream_t) nullptr);
@@ -1042,6 +1213,9 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
         ctx->last_unique_queries = (int)nq;
         ctx->last_flagged = 0;
         ctx->last_pass_launches = ctx->last_pass_queues = 0;
+        ctx->paths.dev = nullptr;
+        ctx->paths.n = nq;
+        ctx->paths.all = FDR_PATH_GENERIC;
         int trc = timing_begin(ctx, FDR_KERNEL_KNN_TILE, st);
         if (trc) return trc;
         hipLaunchKernelGGL(knn_generic_kernel, dim3((unsigned)((nq + GEN_QPB - 1) / GEN_QPB)), dim3(256),
@@ -1163,8 +1337,12 @@ static int launch_knn(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_qzero,
     const int xw = expand_waves_per_block(k), xq = xw * (64 / k) * EXPAND_UNROLL;  // (k <= FDR_FAST_MAX_K = 64 here)
     hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)((nq + xq - 1) / xq)), dim3(64 * xw), (size_t)xw * k * k * 8, st, q0, (int)nq, k, 64 / k,
                        (int)t_base, (const int *)cls, (const int *)uofc, (const int *)uqpos, (const int *)idx_u,
-                       (const float *)dist_u, (const int *)idx_s, (const int4 *)hash, d_idx, d_dist, k);
+                       (const float *)dist_u, (const int *)idx_s, (const int4 *)hash, d_idx, d_dist, k,
+                       ctx->paths.n == nuq ? ctx->paths.dev : nullptr, ctx->paths.all, (uint8_t *)(ws + L.off_rowpath));
     HIP_TRY(hipGetLastError());
+    ctx->paths.dev = (const uint8_t *)(ws + L.off_rowpath);  // (the unique rows' codes, carried to the rows of their classes)
+    ctx->paths.n = nq;
+    ctx->paths.stream = st;
     return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
 }
 
@@ -1268,6 +1446,10 @@ FDR_EXPORT int fdr_knn_unique_dev(fdr_ctx *ctx, int64_t u_lo, int64_t u_hi, int3
     const float *U = (const float *)(ws + L.off_U);
     const uint8_t *uzero = (const uint8_t *)(ws + L.off_uzero);
     ctx->last_unique_queries = (int)(u_hi - u_lo);
+    struct NoPaths {  // (fdr_last_query_paths covers whole calls; a share of the unique rows is not one)
+        fdr_ctx *c;
+        ~NoPaths() { c->paths.n = 0; }
+    } no_paths{ctx};
     // the unique rows are stored in ascending representative order; a share of them is a block of U
     return launch_knn_mode(ctx, U + (size_t)u_lo * dp, uzero + u_lo, u_hi - u_lo, U, uzero, ctx->cls.nu, 0, ctx->cls.d,
                            ctx->cls.k, d_idx_u, d_dist_u, ctx->cls.ws, L.inner_bytes, (hipStream_t)stream);
@@ -1294,8 +1476,10 @@ FDR_EXPORT int fdr_knn_expand_dev(fdr_ctx *ctx, int64_t q0, int64_t nq, int64_t 
     hipLaunchKernelGGL(expand_classes_kernel, dim3((unsigned)((nq + xq - 1) / xq)), dim3(64 * xw), (size_t)xw * k * k * 8, st, (int)q0, (int)nq, k,
                        64 / k, (int)t_base, (const int *)(ws + L.off_cls), (const int *)(ws + L.off_uofc), (const int *)nullptr,
                        (const int *)d_idx_u_all, d_dist_u_all, (const int *)(ws + L.off_idx_s),
-                       (const int4 *)(ws + L.off_hash), d_idx, d_dist, (int)u_row_stride);
+                       (const int4 *)(ws + L.off_hash), d_idx, d_dist, (int)u_row_stride, (const uint8_t *)nullptr,
+                       (uint8_t)0, (uint8_t *)nullptr);
     HIP_TRY(hipGetLastError());
+    ctx->paths.n = 0;  // (the unique rows were searched by several ranks: no codes)
     return timing_end(ctx, FDR_KERNEL_KNN_DEDUP, st);
 }
 
@@ -1347,6 +1531,156 @@ static int upload_csr(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr,
     return FDR_OK;
 }
 
+// Host CSR -> E (device, [n_rows, d]) on ctx->stream: see host_upload.inc.  Small inputs take the plain path.
+static int upload_embed_pipelined(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr, const int32_t *a_indices,
+                                  float *d_E) {
+    int rc;
+    const int64_t nnz = a_indptr[n_rows];
+    const int d = ctx->d;
+    const int64_t min_ids = 1 << 20;  // below 4 MB of ids there is nothing to overlap
+    const int nthr = std::max(1, std::min(host_cpu_budget() - 1, 31));  // (the calling thread drives the link)
+    if (nnz < min_ids || ctx->h_bits.empty()) {
+        if ((rc = upload_csr(ctx, n_rows, a_indptr, a_indices))) return rc;
+        return launch_embed(ctx, n_rows, (const int64_t *)ctx->a_indptr.p, (const int32_t *)ctx->a_indices.p, d_E, ctx->stream);
+    }
+    // chunks of ~T ids, cut at row boundaries by bisection of the (monotone) row pointers
+    const int64_t T = std::max<int64_t>(1 << 18, std::min<int64_t>(1 << 21, nnz / 64));
+    std::vector<hup::Chunk> chunks;
+    for (int64_t r = 0; r < n_rows;) {
+        const int64_t want = a_indptr[r] + T;
+        int64_t r1 = std::upper_bound(a_indptr + r + 1, a_indptr + n_rows + 1, want) - a_indptr;  // first row END beyond `want`
+        r1 = std::min(n_rows, std::max(r + 1, r1 - 1 > r ? r1 - 1 : r + 1));
+        hup::Chunk c;
+        c.r0 = r;
+        c.r1 = r1;
+        chunks.push_back(c);
+        r = r1;
+    }
+    const int64_t nch = (int64_t)chunks.size();
+    for (const hup::Chunk &c : chunks)
+        if (a_indptr[c.r0] < 0 || a_indptr[c.r1] < a_indptr[c.r0] || a_indptr[c.r1] > nnz)
+            return fail(FDR_E_ARG, "embed: indptr not monotone near row %lld", (long long)c.r0);
+    const int64_t stage_cap = std::max<int64_t>(1 << 20, nnz / 6);  // ids of pinned staging (P keeps ~5 % of them)
+    if ((rc = ctx->a_indptr.reserve((size_t)(n_rows + 1) * 8))) return rc;
+    if ((rc = ctx->a_indices.reserve((size_t)nnz * 4))) return rc;
+    if ((rc = ctx->c_indptr.reserve((size_t)(n_rows + nch + 1) * 8))) return rc;
+    if ((rc = ctx->c_indices.reserve((size_t)stage_cap * 4))) return rc;
+    if ((rc = ctx->stage_ids.reserve((size_t)stage_cap * 4))) return rc;
+    if ((rc = ctx->stage_ptr.reserve((size_t)(n_rows + nch + 1) * 8))) return rc;
+    for (hipEvent_t &e : ctx->up_ev)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    int32_t *stage_ids = (int32_t *)ctx->stage_ids.p;
+    int64_t *stage_ptr = (int64_t *)ctx->stage_ptr.p;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->a_indptr.p, a_indptr, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, st));
+
+    // the two fronts: chunks [front, back) are unclaimed
+    std::atomic<uint64_t> ends{(uint64_t)nch};  // front << 32 | back
+    auto claim = [&](bool from_back) -> int64_t {
+        uint64_t v = ends.load();
+        for (;;) {
+            const uint64_t f = v >> 32, b = v & 0xffffffffull;
+            if (f >= b) return -1;
+            const uint64_t nv = from_back ? (f << 32 | (b - 1)) : ((f + 1) << 32 | b);
+            if (ends.compare_exchange_weak(v, nv)) return (int64_t)(from_back ? b - 1 : f);
+        }
+    };
+    std::atomic<int64_t> stage_used{0};
+    std::atomic<bool> stage_full{false};
+    std::atomic<int64_t> bad_row{-1};
+    const uint32_t *bw = ctx->h_bits.data();
+    const uint64_t F = (uint64_t)ctx->n_features;
+    auto worker = [&]() {
+        std::vector<int32_t> scratch;
+        while (!stage_full.load()) {
+            const int64_t ci = claim(true);
+            if (ci < 0) break;
+            hup::Chunk &c = chunks[(size_t)ci];
+            const int64_t raw = a_indptr[c.r1] - a_indptr[c.r0];
+            for (int64_t r = c.r0; r < c.r1; ++r)
+                if (a_indptr[r + 1] < a_indptr[r]) {
+                    int64_t exp = -1;
+                    bad_row.compare_exchange_strong(exp, r);
+                }
+            if (bad_row.load() >= 0) break;
+            if ((int64_t)scratch.size() < raw) scratch.resize((size_t)raw);
+            int64_t *ptr = stage_ptr + c.r0 + ci;  // (chunk ci's rows + 1 pointers: disjoint from every other chunk's)
+            const int64_t n = hup::compact_chunk(bw, F, a_indptr, a_indices, c.r0, c.r1, scratch.data(), raw, ptr);
+            const int64_t off = stage_used.fetch_add(n);
+            if (off + n > stage_cap) {  // (P keeps far more ids than expected: this chunk and the rest go raw)
+                stage_full.store(true);
+                c.staged_off = -2;
+                break;
+            }
+            memcpy(stage_ids + off, scratch.data(), (size_t)n * 4);
+            c.staged_off = off;
+            c.staged_n = n;
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 0; t < nthr; ++t) pool.emplace_back(worker);
+    } catch (...) {  // (fewer helpers than hoped: the link carries more)
+    }
+    auto send_raw = [&](const hup::Chunk &c, int slot) -> int {
+        const int64_t o = a_indptr[c.r0], len = a_indptr[c.r1] - o;
+        if (len > 0)
+            HIP_TRY(hipMemcpyAsync((int32_t *)ctx->a_indices.p + o, a_indices + o, (size_t)len * 4, hipMemcpyHostToDevice, st));
+        int erc = launch_embed(ctx, c.r1 - c.r0, (const int64_t *)ctx->a_indptr.p + c.r0, (const int32_t *)ctx->a_indices.p,
+                               d_E + (size_t)c.r0 * d, st);
+        if (erc) return erc;
+        if (slot >= 0) HIP_TRY(hipEventRecord(ctx->up_ev[slot], st));
+        return FDR_OK;
+    };
+    int urc = FDR_OK;
+    int64_t sent = 0;
+    for (; urc == FDR_OK; ++sent) {
+        if (sent >= 2) {  // two chunks in flight: the next is claimed when the link has taken the one before the last
+            hipError_t e = hipEventSynchronize(ctx->up_ev[sent & 1]);
+            if (e != hipSuccess) {
+                urc = fail(FDR_E_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(e));
+                break;
+            }
+        }
+        const int64_t ci = claim(false);
+        if (ci < 0) break;
+        urc = send_raw(chunks[(size_t)ci], (int)(sent & 1));
+    }
+    for (std::thread &t : pool) t.join();
+    if (urc) return urc;
+    if (bad_row.load() >= 0) return fail(FDR_E_ARG, "embed: indptr not monotone at row %lld", (long long)bad_row.load());
+    // what the helpers left: chunks they could not stage go raw; the staged ids and row pointers follow in two copies
+    const int64_t used = std::min<int64_t>(stage_used.load(), stage_cap);
+    bool any_staged = false;
+    for (int64_t ci = 0; ci < nch; ++ci) {
+        hup::Chunk &c = chunks[(size_t)ci];
+        const uint64_t v = ends.load();
+        const bool claimed = (uint64_t)ci < (v >> 32) || (uint64_t)ci >= (v & 0xffffffffull);
+        if (c.staged_off >= 0) any_staged = true;
+        else if (c.staged_off == -2 || !claimed) {  // dropped by a helper, or never claimed (helpers stopped early)
+            if ((rc = send_raw(c, -1))) return rc;
+        }
+    }
+    if (any_staged) {
+        if (used > 0)
+            HIP_TRY(hipMemcpyAsync(ctx->c_indices.p, stage_ids, (size_t)used * 4, hipMemcpyHostToDevice, st));
+        // (the pointers of the staged chunks only: they lie at the back, from the first staged chunk's slot on)
+        int64_t first = nch;
+        for (int64_t ci = 0; ci < nch; ++ci)
+            if (chunks[(size_t)ci].staged_off >= 0) { first = ci; break; }
+        const int64_t p0 = chunks[(size_t)first].r0 + first, p1 = n_rows + nch;
+        HIP_TRY(hipMemcpyAsync((int64_t *)ctx->c_indptr.p + p0, stage_ptr + p0, (size_t)(p1 - p0) * 8, hipMemcpyHostToDevice, st));
+        for (int64_t ci = first; ci < nch; ++ci) {
+            const hup::Chunk &c = chunks[(size_t)ci];
+            if (c.staged_off < 0) continue;
+            if ((rc = launch_embed(ctx, c.r1 - c.r0, (const int64_t *)ctx->c_indptr.p + c.r0 + ci,
+                                   (const int32_t *)ctx->c_indices.p + c.staged_off, d_E + (size_t)c.r0 * d, st)))
+                return rc;
+        }
+    }
+    return FDR_OK;
+}
+
 FDR_EXPORT int fdr_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr,
                          const int32_t *a_indices, float *E_out) {
     int rc = use_device(ctx);
@@ -1355,12 +1689,9 @@ FDR_EXPORT int fdr_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indptr,
     if (ctx->n_features <= 0) return fail(FDR_E_STATE, "embed: no projection loaded");
     if (n_rows == 0) return FDR_OK;
     if (!E_out) return fail(FDR_E_ARG, "embed: E_out is null");
-    if ((rc = upload_csr(ctx, n_rows, a_indptr, a_indices))) return rc;
     const size_t ebytes = (size_t)n_rows * ctx->d * 4;
     if ((rc = ctx->E.reserve(ebytes))) return rc;
-    if ((rc = launch_embed(ctx, n_rows, (const int64_t *)ctx->a_indptr.p,
-                           (const int32_t *)ctx->a_indices.p, (float *)ctx->E.p, ctx->stream)))
-        return rc;
+    if ((rc = upload_embed_pipelined(ctx, n_rows, a_indptr, a_indices, (float *)ctx->E.p))) return rc;
     HIP_TRY(hipMemcpyAsync(E_out, ctx->E.p, ebytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FDR_OK;
@@ -1412,12 +1743,9 @@ FDR_EXPORT int fdr_embed_knn(fdr_ctx *ctx, int64_t n_rows, const int64_t *a_indp
     if ((rc = check_csr(n_rows, a_indptr, a_indices))) return rc;
     if (ctx->n_features <= 0) return fail(FDR_E_STATE, "embed: no projection loaded");
     if (n_rows <= 0) return fail(FDR_E_ARG, "embed_knn: empty input");
-    if ((rc = upload_csr(ctx, n_rows, a_indptr, a_indices))) return rc;
     const size_t ebytes = (size_t)n_rows * ctx->d * 4;
     if ((rc = ctx->E.reserve(ebytes))) return rc;
-    if ((rc = launch_embed(ctx, n_rows, (const int64_t *)ctx->a_indptr.p,
-                           (const int32_t *)ctx->a_indices.p, (float *)ctx->E.p, ctx->stream)))
-        return rc;
+    if ((rc = upload_embed_pipelined(ctx, n_rows, a_indptr, a_indices, (float *)ctx->E.p))) return rc;
     if (E_out) HIP_TRY(hipMemcpyAsync(E_out, ctx->E.p, ebytes, hipMemcpyDeviceToHost, ctx->stream));
     return knn_from_device_E(ctx, (const float *)ctx->E.p, n_rows, ctx->d, k, idx_out, dist_out);
 }

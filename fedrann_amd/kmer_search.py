@@ -285,24 +285,36 @@ def kmer_searcher(kmer_lib, input_reads, output_dir, k, threads=None, context=No
     os.makedirs(output_dir, exist_ok=True)
     freq = np.zeros(int(codes.size), dtype=np.int64)
     all_ids, ptr_parts, idx_parts, n_reads, nnz = [], [np.zeros(1, dtype=np.int64)], [], 0, 0
-    out_bin = os.path.join(output_dir, "output.bin")
-    with open(out_bin, "wb") as f:
-        f.write(struct.pack("<4sB3sQ", b"KMER", 1, b"\0\0\0", 0))
-    for ids, seqs, off in iter_sequence_blocks(input_reads, fastq_ids_as_fasta=fastq_ids_as_fasta,
-                                               chunk_bytes=chunk_bytes, reuse_buffers=True):
-        indptr, indices = search(seqs, off, codes, k, context=context)
-        _lib.kmer_output_append(out_bin, ids, indptr, indices)  # (native: no per-record Python)
-        if indices.size:
-            freq += np.bincount(indices, minlength=freq.size)
-        if collect:
-            all_ids += ids
-            ptr_parts.append(indptr[1:] + nnz)
-            idx_parts.append(indices)
-        n_reads += len(ids)
-        nnz += int(indices.size)
-    with open(out_bin, "r+b") as f:  # the record count, known now
-        f.seek(8)
-        f.write(struct.pack("<Q", n_reads))
+    # The records go to output.bin.tmp, which becomes output.bin once the header holds the record count: a piece that
+    # fails (an id fdr_kmer_output_append refuses, a GPU error) leaves no output.bin with a VALID header saying "0
+    # records" behind for a later --kmer-searcher-output run to take for an empty read set.
+    final_bin = os.path.join(output_dir, "output.bin")
+    out_bin = final_bin + ".tmp"
+    if os.path.exists(final_bin):
+        os.remove(final_bin)
+    try:
+        with open(out_bin, "wb") as f:
+            f.write(struct.pack("<4sB3sQ", b"KMER", 1, b"\0\0\0", 0))
+        for ids, seqs, off in iter_sequence_blocks(input_reads, fastq_ids_as_fasta=fastq_ids_as_fasta,
+                                                   chunk_bytes=chunk_bytes, reuse_buffers=True):
+            indptr, indices = search(seqs, off, codes, k, context=context)
+            _lib.kmer_output_append(out_bin, ids, indptr, indices)  # (native: no per-record Python)
+            if indices.size:
+                freq += np.bincount(indices, minlength=freq.size)
+            if collect:
+                all_ids += ids
+                ptr_parts.append(indptr[1:] + nnz)
+                idx_parts.append(indices)
+            n_reads += len(ids)
+            nnz += int(indices.size)
+        with open(out_bin, "r+b") as f:  # the record count, known now
+            f.seek(8)
+            f.write(struct.pack("<Q", n_reads))
+        os.replace(out_bin, final_bin)
+    except BaseException:
+        if os.path.exists(out_bin):
+            os.remove(out_bin)
+        raise
     nz = np.flatnonzero(freq)
     out = np.empty((nz.size, 2), dtype="<u8")
     out[:, 0] = nz

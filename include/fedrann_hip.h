@@ -199,6 +199,22 @@ int fdr_last_prefilter_launches(fdr_ctx *ctx, int *launches, int *queues);
 /* Prefilter mode only: number of query rows of the most recent k-NN call whose candidate set could
  * not be certified and that were therefore searched by the exact kernel. */
 int fdr_last_uncertified(fdr_ctx *ctx);
+/* Diagnostics: which way each query row of the most recent fdr_knn_dev / fdr_knn / fdr_embed_knn call took to its
+ * (canonical, identical on every way) result -- one byte per query row, copied to host memory `paths` [n_queries]:
+ * the low seven bits one of FDR_PATH_*, bit 7 (FDR_PATH_CLASS_MEMBER) set when the row belongs to a duplicate-row
+ * class of several rows and its result was expanded from the class representative's.  The codes live in the
+ * workspace of that call: ask before the workspace is reused or freed, with the n_queries of that call
+ * (FDR_E_STATE otherwise, and after fdr_knn_unique_dev / fdr_knn_expand_dev, which record none).  The parity
+ * tests stratify their oracle samples by these codes; nothing in the product reads them. */
+#define FDR_PATH_NONE 0            /* (never reported for a finished row) */
+#define FDR_PATH_CERTIFIED 1       /* fp16 candidates certified, the K' candidates re-ranked with the canonical chain */
+#define FDR_PATH_RANGE 2           /* plateau: every target within the bound collected by the range pass, ranked exactly */
+#define FDR_PATH_EXACT 3           /* the exact fp32 kernel (exact mode; uncertifiable queries of the prefilter mode) */
+#define FDR_PATH_ZERO 4            /* all-zero query row: closed-form answer */
+#define FDR_PATH_RANGE_OVERFLOW 5  /* the range pass collected more than its capacity: the exact kernel */
+#define FDR_PATH_GENERIC 6         /* d > 512 or k > 64: the generic kernel */
+#define FDR_PATH_CLASS_MEMBER 0x80
+int fdr_last_query_paths(fdr_ctx *ctx, uint8_t *paths, int64_t n_queries);
 
 /* ---- k-mer search on the GPU: reads x k-mer library -> per-read set of library indices -----------
  * Replaces the reference's native tool kmer_searcher (kmer_searcher/kmer_searcher.cpp:232-375; called
@@ -300,7 +316,9 @@ int fdr_kmer_output_append(const char *path, int64_t n_records, const int64_t *n
  * byte for byte what pandas writes for the reference's DataFrame (float32 distances in their shortest
  * round-trip form, numpy layout; a negative t aliases from the end like Python indexing).  idx / dist
  * [n_rows, k] are the rows row0 .. row0 + n_rows of the neighbour graph (a rank's block of a row-sharded
- * run); names / name_off / strands describe all n_total rows.  append: open the file for appending;
+ * run); names / name_off / strands describe all n_total rows -- or, with strands == NULL, names / name_off describe
+ * the n_total / 2 RECORDS of a fwd / rev doubled matrix (feature_extraction.py:136-140): row t carries record t >> 1's
+ * id and strand t & 1, and no id is held twice.  append: open the file for appending;
  * write_header: the column-name line first.  n_threads <= 0: all hardware threads.  *lines_out (may be
  * NULL) = data lines written. */
 int fdr_overlaps_write(const char *path, int32_t append, int32_t write_header, int64_t n_total, int64_t row0,

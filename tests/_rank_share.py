@@ -8,8 +8,8 @@ tests/test_gpu_configs.py and devtools/rank_share_real.py):
                    blocks in pieces on the same GPU (what the all-gather would deliver)
   k-NN             fdr_normalize_dev + fdr_knn_dev: queries = the rank's block, targets = all N rows
 
-Parity: the rank's block of E against orc_embed bit for bit; a sample of query rows against the exact CPU
-oracle over ALL targets -- the targets are streamed back from HBM in pieces of <= 1 M rows and the per-piece
+Parity: the rank's block of E against orc_embed bit for bit; query rows sampled PER EXECUTION PATH (tests/_strata.py:
+fdr_last_query_paths) against the exact CPU oracle over ALL targets -- the targets are streamed back from HBM in pieces of <= 1 M rows and the per-piece
 top-k lists merged on the host by (distance bits, index), so host memory stays around 1-2 GB; whole-result
 properties on every row."""
 import os
@@ -29,7 +29,7 @@ def host_threads(per_thread_gb=3.0):
     return n
 
 
-def run_rank_share(ctx, oracle, R, d, k, doubling, ranks=8, rank=0, sample=192, piece_reads=1_600_000, seed=602,
+def run_rank_share(ctx, oracle, R, d, k, doubling, ranks=8, rank=0, sample=64, piece_reads=1_600_000, seed=602,
                    reps=1, log=None):
     import torch
     from fedrann_amd.distributed import HipEngine, shard_rows
@@ -133,7 +133,19 @@ def run_rank_share(ctx, oracle, R, d, k, doubling, ranks=8, rank=0, sample=192, 
                 node_read_pairs_per_s_if_every_rank_takes_as_long=n * k / best,
                 prefilter_pflops_on_unique_rows=(2.0 * ut * uq * d / (info["kernels_ms"]["knn_prefilter"] * 1e-3) / 1e15
                                                  if info["kernels_ms"].get("knn_prefilter") else None))
-    del Ehat
+    paths = ctx.last_query_paths(nq)  # (before the workspace is used again)
+    # rows of the block that share their normalised row, bit for bit, with another row of the matrix -- counted
+    # independently of the library (a 64-bit hash of the row's bits, torch on the device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(12345)
+    w = torch.randint(-(2 ** 62), 2 ** 62, (dp,), dtype=torch.int64, device=dev, generator=g) | 1
+    hsh = torch.empty((n,), dtype=torch.int64, device=dev)
+    for c0 in range(0, n, 1 << 20):
+        c1 = min(n, c0 + (1 << 20))
+        hsh[c0:c1] = (Ehat[c0:c1].view(torch.int32).to(torch.int64) * w).sum(1)
+    _, inv, mult = torch.unique(hsh, return_inverse=True, return_counts=True)
+    members_expected = int((mult[inv[lo:hi]] > 1).sum().item())
+    del Ehat, hsh, inv, mult
     idx_h, dst_h = idx.cpu().numpy(), dst.cpu().numpy()
     del idx, dst
 
@@ -146,10 +158,15 @@ def run_rank_share(ctx, oracle, R, d, k, doubling, ranks=8, rank=0, sample=192, 
     # ---- sampled exact oracle over ALL targets, targets streamed back in pieces --------------------------------
     t0 = time.perf_counter()
     zero_h = zero.cpu().numpy()
-    rng = np.random.default_rng(1)
-    zr = lo + np.flatnonzero(zero_h[lo:hi])[:16]
-    rows = np.unique(np.concatenate([lo + rng.choice(nq, size=min(sample, nq), replace=False), zr,
-                                     [lo, lo + 1, hi - 2, hi - 1]])).astype(np.int64)
+    # the oracle's rows: up to `sample` from EVERY execution path the library reports for this call (tests/_strata.py:
+    # certified, range pass, exact kernel, all-zero, member of a duplicate-row class, a plateau query inside a class,
+    # the block's first / last rows) -- a uniform sample of a few hundred rows meets the rare paths by chance only
+    from _strata import stratified_rows
+    picked, path_counts, path_taken = stratified_rows(paths, per=sample, seed=1)
+    rows = lo + picked
+    info.update(path_counts=path_counts, path_rows_sampled=path_taken, path_sample_per_stratum=sample,
+                path_zero_count_matches_flags=bool(path_counts["zero"] == int(zero_h[lo:hi].sum())),
+                path_class_members_match_row_hashes=bool(path_counts["class_member"] == members_expected))
     Eq = E_all[torch.from_numpy(rows).to(dev)].cpu().numpy()
     Qh, _, qz = oracle.normalize(Eq)
     keys = []
@@ -179,3 +196,10 @@ def assert_rank_share(info):
     assert info["keys_strictly_ascending"] and info["values_in_range"]
     assert info["identical_indices"], "neighbour indices differ from the oracle"
     assert info["identical_distance_bits"], "distance bits differ from the oracle"
+    # the strata: the codes partition the rows (checked when they are drawn), agree with what is known independently
+    # of the library, and every path this workload exercises gave the oracle its rows
+    assert info["path_zero_count_matches_flags"] and info["path_class_members_match_row_hashes"]
+    c, t = info["path_counts"], info["path_rows_sampled"]
+    for name in c:
+        assert t[name] == min(c[name], info["path_sample_per_stratum"]), (name, c, t)
+    assert c["certified"] > 0 and c["range"] >= 64 and c["zero"] > 0 and c["class_member"] >= 64, c

@@ -101,7 +101,7 @@ def test_config4_real_generator_one_rank_share_full_size(ctx, oracle):
 def test_config5_real_generator_one_rank_share_full_size(ctx, oracle):
     """Config 5 as BASELINE states it, one rank's share at full size: 10 M reads with fwd / rev doubling = 20 M
     rows (39 target segments of 48), d = 256, k = 50 (K' = 58), 2.5 M query rows."""
-    info = _real_rank_share(ctx, oracle, "config5", R=10_000_000, d=256, k=50, doubling=True, sample=128)
+    info = _real_rank_share(ctx, oracle, "config5", R=10_000_000, d=256, k=50, doubling=True, sample=64)
     assert info["rows"] == 20_000_000 and info["query_rows"] == 2_500_000
     assert info["unique_targets"] <= 20_000_000
 

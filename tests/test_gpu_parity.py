@@ -135,6 +135,29 @@ def test_embed_dense_projection_rows(ctx, oracle):
     assert np.array_equal(_bits(E), _bits(want))
 
 
+def test_embed_host_upload_in_chunks_raw_and_compacted(ctx, oracle):
+    """fdr_embed's pipelined upload (host_upload.inc: raw chunks from the front over PCIe, chunks compacted by host
+    threads from the back) on inputs above its 1 M-id threshold: a sparse projection (the helpers' chunks fit the
+    staging buffer), a dense one (every id survives: the staging buffer overflows and the chunks go raw after all), rows
+    without ids and one very long row.  E = the oracle's bits either way."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(14)
+    for F, dens, nrows in ((200_000, 0.0005, 30_000), (4096, 0.6, 24_000)):
+        P = sp.random(F, 128, density=dens, format="csr", dtype=np.float32, random_state=5,
+                      data_rvs=lambda n: rng.standard_normal(n).astype(np.float32))
+        P.sort_indices()
+        lens = rng.integers(0, 160, size=nrows)
+        lens[7] = 0
+        lens[nrows // 2] = min(F, 60_000)
+        rows = [np.sort(rng.choice(F, size=int(n), replace=False)) for n in lens]
+        indptr, indices = oracle.rows_to_csr(rows)
+        assert indices.size > (1 << 20)
+        ctx.projection_load(P.indptr, P.indices, P.data, F, 128)
+        E = ctx.embed(indptr, indices.astype(np.int32))
+        want = oracle.embed(indptr, indices, (P.indptr, P.indices, P.data), F, 128)
+        assert np.array_equal(_bits(E), _bits(want))
+
+
 # ---- k-NN ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,d,k", [(2000, 128, 20), (777, 128, 20), (3000, 64, 20), (1200, 200, 50),
                                    (900, 256, 50), (300, 128, 1), (513, 100, 64), (64, 128, 64),
@@ -230,13 +253,25 @@ def test_knn_one_million_rows_sampled_oracle(ctx, oracle, knn_mode):
     key = _bits(dist).astype(np.uint64) << np.uint64(32) | idx.astype(np.uint64)
     assert np.all(key[:, 1:] > key[:, :-1])
     assert idx.min() >= 0 and idx.max() < n and dist.min() >= 0 and dist.max() <= 1
-    rng = np.random.default_rng(3)
-    zero_rows = np.flatnonzero(np.abs(E).sum(1) == 0)
-    rows = np.unique(np.concatenate([rng.choice(n, size=320, replace=False), zero_rows[:32],
-                                     np.array([0, 1, n - 2, n - 1])]))
     want_E = oracle.embed(s["indptr"], s["indices"], (P.indptr, P.indices, P.data), s["n_features"], 128)
     assert np.array_equal(_bits(E), _bits(want_E))
     Eh, _, zero = oracle.normalize(E)
+    # the oracle's rows: >= 64 from EVERY execution path the library reports for this call (tests/_strata.py)
+    from _strata import stratified_rows
+    paths = ctx.last_query_paths(n)
+    rows, counts, taken = stratified_rows(paths, per=64, seed=3)
+    # rows in a duplicate-row class of several rows, counted independently (bitwise-equal normalised rows)
+    _, inv, mult = np.unique(np.ascontiguousarray(Eh).view(np.dtype((np.void, Eh.shape[1] * 4))).ravel(),
+                             return_inverse=True, return_counts=True)
+    assert counts["class_member"] == int((mult[inv] > 1).sum()) and counts["class_member"] > 64
+    if knn_mode.startswith("prefilter"):
+        assert counts["zero"] == int(zero.sum()) and counts["zero"] > 64
+        assert counts["certified"] > 0.9 * (n - counts["zero"]) and counts["range"] >= 64 and counts["range_in_class"] > 0
+        assert taken["certified"] == 64 and taken["range"] == 64 and taken["zero"] == 64 and taken["class_member"] == 64
+    else:
+        assert counts["exact"] == n  # (exact mode: every row, the all-zero ones too, goes through the fp32 kernel)
+        zr = np.flatnonzero(zero)[:32]
+        rows = np.unique(np.concatenate([rows, zr]))
     wi, wd = oracle.knn_normalized(Eh[rows], zero[rows], Eh, zero, 20)
     _assert_knn_equal((idx[rows], dist[rows]), (wi, wd))
 

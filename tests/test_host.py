@@ -327,7 +327,7 @@ def test_native_output_bin_loader_record_range(tmp_path, oracle, threads):
     """fdr_kmer_output_load_range: one rank's block of rows (records [lo, hi)) equals the slice of the whole
     matrix, the names are those of all records, empty and out-of-range blocks are handled."""
     from fedrann_amd import _lib
-    from fedrann_amd.__main__ import doubled_names
+    from fedrann_amd.__main__ import record_names
     rng = np.random.default_rng(11)
     L, R = 5000, 700
     path = tmp_path / "output.bin"
@@ -348,18 +348,35 @@ def test_native_output_bin_loader_record_range(tmp_path, oracle, threads):
         assert np.array_equal(boff, noff) and np.array_equal(bbuf, nbuf)
     total, bip, bix, boff, bbuf = _lib.kmer_output_load_range(str(path), 2 * L, 10, 20, with_names=False)
     assert boff is None and bbuf is None and bip.size == 21
-    # the writer's view of the names: every record twice
-    off2, buf2 = doubled_names(noff, nbuf)
-    want = [bytes(nbuf[noff[r]:noff[r + 1]]) for r in range(R) for _ in (0, 1)]
-    assert [bytes(buf2[off2[i]:off2[i + 1]]) for i in range(2 * R)] == want
+    assert _lib.kmer_output_records(str(path)) == R
+    # the writer's view of the names: the records' own (valid UTF-8 ids pass through, nothing is doubled)
+    off1, buf1 = record_names(noff, nbuf)
+    assert off1 is noff and buf1 is nbuf
 
 
-def test_doubled_names_follow_the_reference_rule_for_invalid_utf8():
+def test_record_names_follow_the_reference_rule_for_invalid_utf8_and_doubled_writer_mode(tmp_path):
+    """Ids that are not valid UTF-8 are rewritten as the reference does (feature_extraction.py:125-128); the writer's
+    doubled-rows mode (strands=None: row t = record t >> 1 on strand t & 1) gives the bytes of the per-row form."""
     from fedrann_amd import _lib
-    from fedrann_amd.__main__ import doubled_names
+    from fedrann_amd.__main__ import record_names
     ids = [b"ok", b"caf\xc3\xa9", b"bad\xff\xfeid", b""]
     off = np.zeros(len(ids) + 1, dtype=np.int64)
     np.cumsum([len(b) for b in ids], out=off[1:])
-    off2, buf2 = doubled_names(off, np.frombuffer(b"".join(ids), dtype=np.uint8))
-    got = [bytes(buf2[off2[i]:off2[i + 1]]) for i in range(2 * len(ids))]
-    assert got == [b"ok", b"ok", "café".encode(), "café".encode(), b"bad__id", b"bad__id", b"", b""]
+    off1, buf1 = record_names(off, np.frombuffer(b"".join(ids), dtype=np.uint8))
+    got = [bytes(buf1[off1[i]:off1[i + 1]]) for i in range(len(ids))]
+    assert got == [b"ok", "café".encode(), b"bad__id", b""]
+    # doubled-rows mode against the same rows spelled out
+    rng = np.random.default_rng(3)
+    R, k = len(ids), 5
+    idx = rng.integers(-2, 2 * R, size=(2 * R, k)).astype(np.int32)
+    dist = rng.random((2 * R, k)).astype(np.float32)
+    off2, buf2 = _lib.pack_names([n.decode() for n in got for _ in (0, 1)])
+    strands = np.tile(np.array([0, 1], dtype=np.uint8), R)
+    a, b = tmp_path / "a.tsv", tmp_path / "b.tsv"
+    na = _lib.overlaps_write(str(a), idx, dist, off2, buf2, strands)
+    nb = _lib.overlaps_write(str(b), idx, dist, off1, buf1, None)
+    assert na == nb and a.read_bytes() == b.read_bytes()
+    # a block of rows (a rank's share) in doubled mode
+    nc = _lib.overlaps_write(str(tmp_path / "c.tsv"), idx[2:6], dist[2:6], off1, buf1, None, row0=2, header=False)
+    want = _lib.overlaps_write(str(tmp_path / "d.tsv"), idx[2:6], dist[2:6], off2, buf2, strands, row0=2, header=False)
+    assert nc == want and (tmp_path / "c.tsv").read_bytes() == (tmp_path / "d.tsv").read_bytes()
