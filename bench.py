@@ -250,23 +250,50 @@ def main():
     chunk = 100_000
     r_lo, r_hi = lo // per, -(-hi // per)
     g_lo = r_lo // chunk * chunk
-    s = synth(R, seed=args.seed, doubling=args.doubling, chunk=chunk, reads=(g_lo, r_hi))
-    skip = lo - g_lo * per
-    ip = np.ascontiguousarray(s["indptr"][skip:skip + (hi - lo) + 1] - s["indptr"][skip])
-    ix = np.ascontiguousarray(s["indices"][s["indptr"][skip]:s["indptr"][skip + (hi - lo)]])
-    P = build_precompute_matrix(s["counts"], d)
-
+    # The rank's rows are generated in pieces of <= 1 M reads and compacted piece by piece (what the product uploads --
+    # python -m fedrann_amd -- is the CSR without the ids P has no entry for: >= 90 % of them, density 1 / sqrt(F); same
+    # E bit for bit, tests); the full CSR is kept too while it is small enough to be the host-to-host pass's and the CPU
+    # baseline's input (10 M reads: 6.8 GB of ids per copy -- the pieces are dropped and those two legs are skipped).
+    keep_full = (r_hi - g_lo) <= 2_000_000
+    piece = 1_000_000
     ctx = _lib.Context(local_rank)
     ctx.set_knn_mode(args.mode)
-    ctx.projection_load(P.indptr, P.indices, P.data, s["n_features"], d)
+    P = None
+    s = None
+    c_ip, c_ix, f_ip, f_ix = [np.zeros(1, dtype=np.int64)], [], [np.zeros(1, dtype=np.int64)], []
+    nnz_total = 0
+    for p0 in range(g_lo, r_hi, piece):
+        p1 = min(r_hi, p0 + piece)
+        sp = synth(R, seed=args.seed, doubling=args.doubling, chunk=chunk, reads=(p0, p1))
+        if P is None:
+            P = build_precompute_matrix(sp["counts"], d)
+            ctx.projection_load(P.indptr, P.indices, P.data, sp["n_features"], d)
+            s = {"n_features": sp["n_features"], "counts": sp["counts"]}
+        a = max(lo, p0 * per) - p0 * per      # this rank's rows of the piece
+        b = min(hi, p1 * per) - p0 * per
+        pip = np.ascontiguousarray(sp["indptr"][a:b + 1] - sp["indptr"][a])
+        pix = np.ascontiguousarray(sp["indices"][sp["indptr"][a]:sp["indptr"][b]])
+        del sp
+        nnz_total += int(pix.size)
+        cip, cix = ctx.csr_compact(pip, pix)
+        c_ip.append(cip[1:] + c_ip[-1][-1])
+        c_ix.append(cix)
+        if keep_full:
+            f_ip.append(pip[1:] + f_ip[-1][-1])
+            f_ix.append(pix)
+        del pip, pix
+    ip = np.concatenate(c_ip)
+    ix = np.concatenate(c_ix) if c_ix else np.zeros(0, dtype=np.int32)
+    del c_ip, c_ix
+    if keep_full:
+        ip_full, ix_full = np.concatenate(f_ip), (np.concatenate(f_ix) if f_ix else np.zeros(0, dtype=np.int32))
+        s.update(indptr=ip_full, indices=ix_full)
+    else:
+        ip_full = ix_full = None
+    del f_ip, f_ix
     engine = HipEngine(ctx, device)
     pipe = ShardedPipeline(engine, n, d, k, rank=rank, world_size=world, device=device)
-    assert (pipe.lo, pipe.hi) == (lo, hi)
-    # what the product uploads (python -m fedrann_amd): the CSR without the ids P has no entry for (>= 90 % of
-    # them, density 1 / sqrt(F)); same E bit for bit (tests), the full matrix stays in feature_matrix.npz
-    nnz_total = int(ix.size)
-    ip_full, ix_full = ip, ix
-    ip, ix = ctx.csr_compact(ip_full, ix_full)
+    assert (pipe.lo, pipe.hi) == (lo, hi) and ip.size == hi - lo + 1
     d_ip = torch.from_numpy(ip).to(device)
     d_ix = torch.from_numpy(ix).to(device)
     nloc = pipe.hi - pipe.lo
@@ -335,7 +362,9 @@ def main():
     # fused host-pointer call (H2D, embed, normalise, k-NN, D2H).  Never `value` (the contract times the
     # device-resident path); same results, checked.
     host_span = None
-    if world == 1 and not args.no_host_span:
+    if world == 1 and not args.no_host_span and not keep_full:
+        host_span = {"skipped": "the full CSR of %d reads is not held on the host (see keep_full)" % R}
+    elif world == 1 and not args.no_host_span:
         h_idx = np.empty((n, k), dtype=np.int32)
         h_dst = np.empty((n, k), dtype=np.float32)
         hsteps = args.host_steps if args.host_steps > 0 else args.steps
@@ -440,7 +469,7 @@ def main():
                           "value_host_to_host = SURVEY 8(d)'s span: CSR in host memory -> (indices, distances) in host memory "
                           "through fdr_embed_knn with the full CSR, PCIe copies inside the timed region, same --steps",
             "value_device": value,
-            "value_host_to_host": (host_span or {}).get("full_csr", {}).get("value"),
+            "value_host_to_host": ((host_span or {}).get("full_csr") or {}).get("value"),
             "host_to_host": host_span,
             "knn_mode": "prefilter" if used_prefilter else "exact",
             "uncertified_queries_last_step": uncertified if used_prefilter else None,
@@ -455,7 +484,7 @@ def main():
             other["roofline"] = mfma_roofline(other["kernels_ms"], other["kernel_launches"], other["mode"] == "prefilter",
                                               timed_mode=False)
             result["other_mode"] = other
-        if world == 1 and args.cpu_baseline_seconds > 0:
+        if world == 1 and args.cpu_baseline_seconds > 0 and keep_full:
             m = min(nloc, 1 << 17)
             base = cpu_baseline(s, P, d, k, args.cpu_baseline_seconds,
                                 gpu_result=(out[0][:m].cpu().numpy(), out[1][:m].cpu().numpy()))

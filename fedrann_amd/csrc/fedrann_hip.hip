@@ -729,10 +729,15 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
     return timing_end(ctx, FDR_KERNEL_KNN_MERGE, st);
 }
 
-// Development builds may compile a subset of the prefilter pass's shapes (-DFDR_SHAPE_MASK=<bits of the FDR_SHAPE_CASE
-// numbers below>, -DFDR_LH_MASK=<16 | 32>): the full set is ten minutes of hipcc.  The release library compiles all.
+// Which of the prefilter pass's shapes are compiled (-DFDR_SHAPE_MASK=<bits of the FDR_SHAPE_CASE numbers below>,
+// -DFDR_LH_MASK=<16 | 32 | 48>): the release library holds the shapes prefilter_shape() chooses by itself, a development
+// build all of them (the round-3 shapes the knobs D256 / PP can put back), or a subset to save minutes of hipcc.
 #ifndef FDR_SHAPE_MASK
+#ifdef FDR_DEV
 #define FDR_SHAPE_MASK 0x7fff
+#else
+#define FDR_SHAPE_MASK 0x24CF  // the shapes prefilter_shape() can choose without a development knob: cases 0-3, 6, 7, 10, 13
+#endif
 #endif
 #ifndef FDR_LH_MASK
 #define FDR_LH_MASK 48
@@ -967,17 +972,18 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             if (sh.nw == 8) FDR_SHAPE_CASE(0, FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512));
             else FDR_SHAPE_CASE(1, FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256));
         } else if (dp == 128) FDR_SHAPE_CASE(2, FDR_LAUNCH_PRE(128, 1, 4, 4, 2));
-        else if (sh.tps == 16 && sh.nw == 8 && sh.wps == 2 && !(dp == 256 && dev_knobs().pp == 0)) {
+        else if (sh.nw == 8 && sh.wps == 2 && (sh.tps == 16 || (dp == 512 && sh.tps == 8)) && dev_knobs().pp != 0) {
             // the ping-pong kernel (knn_prefilter_pp.inc)
-#define FDR_LAUNCH_PP(DP_)                                                                               \
-    do {                                                                                                 \
-        if (kp <= 32) FDR_LH_CASE(16, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<DP_, 8, 16>), 512));     \
-        else FDR_LH_CASE(32, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<DP_, 8, 32>), 512));              \
-    } while (0)
-            if (dp == 128) FDR_SHAPE_CASE(12, FDR_LAUNCH_PP(128));
-            else if (dp == 256) FDR_SHAPE_CASE(3, FDR_LAUNCH_PP(256));
-            else FDR_SHAPE_CASE(13, FDR_LAUNCH_PP(512));
-#undef FDR_LAUNCH_PP
+            if (dp == 256) {
+                if (kp <= 32) FDR_SHAPE_CASE(3, FDR_LH_CASE(16, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<256, 8, 16>), 512)));
+                else FDR_SHAPE_CASE(3, FDR_LH_CASE(32, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<256, 8, 32>), 512)));
+            } else if (dp == 512 && sh.tps == 16 && kp <= 32) {
+                FDR_SHAPE_CASE(13, FDR_LH_CASE(16, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<512, 8, 16>), 512)));
+            } else if (dp == 512 && sh.tps == 8 && kp > 32) {
+                FDR_SHAPE_CASE(13, FDR_LH_CASE(32, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<512, 4, 32>), 512)));
+            } else {
+                return fail(FDR_E_STATE, "knn prefilter: no ping-pong kernel for d = %d, K' = %d, ring of %d units", d, kp, sh.tps);
+            }
         } else if (dp == 256 && sh.tps == 16 && sh.nw == 8) FDR_SHAPE_CASE(14, FDR_LAUNCH_PRE(256, 1, 8, 2, 8));
         else if (dp == 256 && sh.tps == 8 && sh.nw == 8) FDR_SHAPE_CASE(4, FDR_LAUNCH_PRE(256, 1, 8, 2, 4));
         else if (dp == 512 && sh.tps == 8 && sh.nw == 8) FDR_SHAPE_CASE(5, FDR_LAUNCH_PRE(512, 1, 8, 2, 4));
@@ -1008,9 +1014,11 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
         HIP_TRY(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_stamps), sizeof(c)));
         for (int w = 0; w < sh.nw; ++w) {
             const double st_n = (double)std::max<unsigned long long>(1, c[w][5]);
-            fprintf(stderr, "[fdr stamps] wave %d: stages %llu  per stage (s_memtime ticks): dma-issue %.0f  mfma+score %.0f  "
-                            "share %.0f  vmcnt(0) %.0f  barrier %.0f\n", w, c[w][5], c[w][0] / st_n, c[w][1] / st_n, c[w][2] / st_n,
-                    c[w][3] / st_n, c[w][4] / st_n);
+            // (knn_prefilter_kernel: 0 dma-issue, 1 mfma+score, 2 share, 3 vmcnt(0), 4 barrier; knn_prefilter_pp_kernel: 0 pipe
+            // turn, 1 dma-issue, 2 scoring, 3 / 4 barrier after the pipe / the other turn, 6 long other turns)
+            fprintf(stderr, "[fdr stamps] wave %d: stages %llu  per stage (s_memtime ticks): ph0 %.0f  ph1 %.0f  ph2 %.0f  ph3 %.0f  "
+                            "ph4 %.0f  long turns %llu\n", w, c[w][5], c[w][0] / st_n, c[w][1] / st_n, c[w][2] / st_n,
+                    c[w][3] / st_n, c[w][4] / st_n, c[w][6]);
         }
         unsigned long long z[16][8] = {};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)));
@@ -1603,9 +1611,9 @@ static int upload_embed_pipelined(fdr_ctx *ctx, int64_t n_rows, const int64_t *a
                     bad_row.compare_exchange_strong(exp, r);
                 }
             if (bad_row.load() >= 0) break;
-            if ((int64_t)scratch.size() < raw) scratch.resize((size_t)raw);
+            if ((int64_t)scratch.size() < raw + 16) scratch.resize((size_t)raw + 16);  // (+ 16: the vector loop stores whole registers)
             int64_t *ptr = stage_ptr + c.r0 + ci;  // (chunk ci's rows + 1 pointers: disjoint from every other chunk's)
-            const int64_t n = hup::compact_chunk(bw, F, a_indptr, a_indices, c.r0, c.r1, scratch.data(), raw, ptr);
+            const int64_t n = csrc::compact_chunk(bw, F, a_indptr, a_indices, c.r0, c.r1, scratch.data(), raw, ptr);
             const int64_t off = stage_used.fetch_add(n);
             if (off + n > stage_cap) {  // (P keeps far more ids than expected: this chunk and the rest go raw)
                 stage_full.store(true);

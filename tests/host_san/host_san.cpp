@@ -235,6 +235,20 @@ static int cmd_tables(unsigned seed, long long F, int d) {
         std::vector<int32_t> o_ix(want_ix.size());  // exactly enough room: one more write would be caught
         rc = csrc::compact(bits, F, n_rows, a_ip.data(), a_ix.data(), o_ip.data(), o_ix.data(), (int64_t)o_ix.size(), threads);
         if (rc || o_ip != want_ip || o_ix != want_ix) return printf("FAIL compact threads=%d rc=%d\n", threads, rc), 1;
+        // the chunk form of the pipelined upload (host_upload.inc; AVX-512 rows where the CPU has them): any row range
+        for (int64_t c0 = 0; c0 < n_rows; c0 += 97) {
+            const int64_t c1 = std::min<int64_t>(n_rows, c0 + 97), raw = a_ip[(size_t)c1] - a_ip[(size_t)c0];
+            std::vector<int32_t> buf((size_t)raw + 16);
+            std::vector<int64_t> ptr((size_t)(c1 - c0) + 1);
+            const int64_t n = csrc::compact_chunk(bits.data(), (uint64_t)F, a_ip.data(), a_ix.data(), c0, c1, buf.data(), raw, ptr.data());
+            if (n != want_ip[(size_t)c1] - want_ip[(size_t)c0]) return printf("FAIL compact_chunk count at row %lld\n", (long long)c0), 1;
+            for (int64_t r = c0; r <= c1; ++r)
+                if (ptr[(size_t)(r - c0)] != want_ip[(size_t)r] - want_ip[(size_t)c0]) return printf("FAIL compact_chunk pointers\n"), 1;
+            if (n > 0 && memcmp(buf.data(), want_ix.data() + want_ip[(size_t)c0], (size_t)n * 4) != 0) return printf("FAIL compact_chunk ids\n"), 1;
+            if (raw > 0 && csrc::compact_chunk(bits.data(), (uint64_t)F, a_ip.data(), a_ix.data(), c0, c1, buf.data(), raw - 1, ptr.data()) != -1 &&
+                n == raw)
+                return printf("FAIL compact_chunk capacity\n"), 1;
+        }
         if (!want_ix.empty() &&
             csrc::compact(bits, F, n_rows, a_ip.data(), a_ix.data(), o_ip.data(), o_ix.data(), (int64_t)o_ix.size() - 1, threads) == FDR_OK)
             return printf("FAIL capacity\n"), 1;
