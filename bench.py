@@ -256,6 +256,12 @@ def main():
     # baseline's input (10 M reads: 6.8 GB of ids per copy -- the pieces are dropped and those two legs are skipped).
     keep_full = (r_hi - g_lo) <= 2_000_000
     piece = 1_000_000
+    gen_threads = cpu_budget()  # (a 100 k-read chunk of the generator holds ~2 GB of temporaries: as many at once as fit)
+    try:
+        import psutil
+        gen_threads = max(2, min(gen_threads, 16, int(psutil.virtual_memory().available / 2**30 / 3.0)))
+    except Exception:
+        gen_threads = max(1, min(gen_threads, 8))
     ctx = _lib.Context(local_rank)
     ctx.set_knn_mode(args.mode)
     P = None
@@ -264,7 +270,7 @@ def main():
     nnz_total = 0
     for p0 in range(g_lo, r_hi, piece):
         p1 = min(r_hi, p0 + piece)
-        sp = synth(R, seed=args.seed, doubling=args.doubling, chunk=chunk, reads=(p0, p1))
+        sp = synth(R, seed=args.seed, doubling=args.doubling, chunk=chunk, reads=(p0, p1), threads=gen_threads)
         if P is None:
             P = build_precompute_matrix(sp["counts"], d)
             ctx.projection_load(P.indptr, P.indices, P.data, sp["n_features"], d)
@@ -417,7 +423,9 @@ def main():
             launches, queues = (max(1, pass_launches), max(1, pass_queues)) if (prefilter and timed_mode) else \
                 (max(1.0, kcnt[name]), 1)
             nominal = 2.0 * nloc * n * d  # every ordered (query row, target row) pair, duplicates included
-            return {"kernel": ("knn_prefilter_kernel (fp16 MFMA 32x32x16)" if prefilter
+            pp_kernel = prefilter and ctx.padded_dim(d) > 128 and launches >= 2 and queues == 2 and timed_mode
+            return {"kernel": (("knn_prefilter_pp_kernel (fp16 MFMA 32x32x16, ping-pong turns)" if pp_kernel else
+                                "knn_prefilter_kernel (fp16 MFMA 32x32x16)") if prefilter
                                else "knn_tile_kernel<%d> (fp32 MFMA 32x32x2)" % ctx.padded_dim(d)),
                     "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "priced_on": "ordered (unique query, unique target) pairs actually evaluated, 2 d flop each",
@@ -441,8 +449,10 @@ def main():
                 with open(path) as f:
                     prof = json.load(f)
                 if prof.get("bench_args") == {"reads": R, "dim": d, "knn": k, "gpus": world, "doubling": args.doubling}:
-                    kname = "knn_prefilter_kernel" if used_prefilter else "knn_tile_kernel"
-                    traffic = prof["pmc_per_launch_avg"][kname]["hbm_bytes_per_launch"]
+                    pmc = prof["pmc_per_launch_avg"]
+                    kname = ("knn_prefilter_pp_kernel" if "knn_prefilter_pp_kernel" in pmc else "knn_prefilter_kernel") \
+                        if used_prefilter else "knn_tile_kernel"
+                    traffic = pmc[kname]["hbm_bytes_per_launch"]
                     traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, bytes "
                                    "per launch, same workload)" % os.path.basename(path))
                     break

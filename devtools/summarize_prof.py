@@ -24,7 +24,7 @@ shutil.copy(os.path.join(src, "prof_%s" % tag, "trace_kernel_stats.csv"),
 
 
 def short(name):
-    for k in ("knn_tile_kernel", "knn_merge_keys_kernel", "knn_merge_kernel", "embed_csr_kernel",
+    for k in ("knn_prefilter_pp_kernel", "knn_range_pp_kernel", "knn_tile_kernel", "knn_merge_keys_kernel", "knn_merge_kernel", "embed_csr_kernel",
               "normalize_rows_kernel", "pack_zero_bits_kernel", "knn_prefilter_kernel", "knn_rerank_kernel",
               "to_half_kernel", "gather_queries_kernel", "scatter_results_kernel", "knn_range_kernel",
               "hash_rows_kernel", "dedup_probe_kernel", "expand_classes_kernel", "zero_answer_kernel"):

@@ -28,6 +28,9 @@
 #include <cstring>
 #include <new>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -228,7 +231,8 @@ struct fdr_ctx {
     DevBuf a_indptr, a_indices, E, Ehat, zero, idx, dist, ws;
     DevBuf c_indptr, c_indices;             // ... the chunks the host compacted (upload_embed_pipelined)
     hup::PinnedBuf stage_ids, stage_ptr;    // ... their pinned staging
-    hipEvent_t up_ev[2] = {nullptr, nullptr};  // ... the two raw chunks in flight
+    hipEvent_t up_ev[2] = {nullptr, nullptr};  // ... the two raw runs in flight
+    hup::WorkerPool up_pool;                // ... the helpers
     // k-mer search (kmer_search.inc)
     DevBuf ks_seq, ks_off, ks_codes, ks_keys, ks_vals, ks_bloom, ks_counter, ks_pairs, ks_pairs2, ks_flag, ks_pos,
         ks_idx, ks_rows, ks_indptr, ks_tmp, kc_counts;
@@ -338,6 +342,7 @@ FDR_EXPORT int fdr_destroy(fdr_ctx *ctx) {
                       &ctx->ks_idx, &ctx->ks_rows, &ctx->ks_indptr, &ctx->ks_tmp, &ctx->kc_counts,
                       &ctx->kc_a0, &ctx->kc_a1, &ctx->kc_c0, &ctx->kc_c1, &ctx->kc_mk, &ctx->kc_mv, &ctx->kc_rc};
     for (DevBuf *b : bufs) b->release();
+    ctx->up_pool.stop();
     ctx->c_indptr.release();
     ctx->c_indices.release();
     ctx->stage_ids.release();
@@ -977,6 +982,9 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             if (dp == 256) {
                 if (kp <= 32) FDR_SHAPE_CASE(3, FDR_LH_CASE(16, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<256, 8, 16>), 512)));
                 else FDR_SHAPE_CASE(3, FDR_LH_CASE(32, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<256, 8, 32>), 512)));
+            } else if (dp == 128) {  // (development: PP = 1)
+                if (kp <= 32) FDR_SHAPE_CASE(12, FDR_LH_CASE(16, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<128, 8, 16>), 512)));
+                else FDR_SHAPE_CASE(12, FDR_LH_CASE(32, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<128, 4, 32>), 512)));
             } else if (dp == 512 && sh.tps == 16 && kp <= 32) {
                 FDR_SHAPE_CASE(13, FDR_LH_CASE(16, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<512, 8, 16>), 512)));
             } else if (dp == 512 && sh.tps == 8 && kp > 32) {
@@ -1082,21 +1090,37 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
                                (const _Float16 *)d_hq, (const float *)d_theta, (const int *)d_rlist, first, c,
                                dp, d_hqc, d_thetac, d_cnt);
             HIP_TRY(hipGetLastError());
-            // (d <= 128, many plateau queries -- 99 k of 916 k at config 4: eight waves per workgroup, half the LDS-DMA
-            // pieces per flop, as in the candidate pass)
-            const int r8 = dev_knobs().range8;
-            const bool wide = dp == 128 && (r8 == 1 || (r8 < 0 && rcount >= 65536));
-            const KnnPlan rp = knn_plan(ctx->num_cus, c, nt, d, 1, wide ? FDR_SHAPE_PREFILTER_W8 : range_shape(dp));  // (k = 1: ring-only LDS)
-            const size_t rlds = (size_t)RANGE_STAGES * 32 * 256 + (size_t)RANGE_LANE_BUF * (wide ? 512 : 256) * 4;  // ring + lane buffers
+            // From 4096 plateau queries (16 blocks of 256, times the plan's segments) the pass runs on the ping-pong
+            // skeleton (knn_range_pp_kernel: eight waves, one workgroup per CU, eight-unit stages); a handful of them (1 M
+            // rows: 1100) keeps round 3's kernel with its many short segments.
+            // (d <= 128, many plateau queries: round 3's eight-wave form, development knob RANGE8 with RANGEPP = 0)
+            const int r8 = dev_knobs().range8, rpp = dev_knobs().rangepp;
+            const bool use_pp = rpp == 1 || (rpp < 0 && c >= 4096);
+            const bool wide = !use_pp && dp == 128 && (r8 == 1 || (r8 < 0 && rcount >= 65536));
+            const KnnPlan rp = knn_plan(ctx->num_cus, c, nt, d, 1, use_pp ? FDR_SHAPE_PP256 : wide ? FDR_SHAPE_PREFILTER_W8 : range_shape(dp));  // (k = 1: ring-only LDS)
+            const size_t rlds = use_pp ? (size_t)16 * 32 * 256 + (size_t)RANGE_LANE_BUF * 512 * 4
+                                       : (size_t)RANGE_STAGES * 32 * 256 + (size_t)RANGE_LANE_BUF * (wide ? 512 : 256) * 4;  // ring + lane buffers
 #define FDR_LAUNCH_RANGE(DP_, NW_, WPS_)                                                                \
     hipLaunchKernelGGL((knn_range_kernel<DP_, NW_, WPS_>), dim3((unsigned)rp.nqb, (unsigned)rp.nseg),      \
                        dim3(64 * NW_), rlds, st, (const _Float16 *)d_hqc, (const float *)d_thetac, c,     \
                        (const _Float16 *)d_ht, (int)nt, (int)t_base, rp.segs, d_cnt, d_rcand)
-            if (wide) FDR_LAUNCH_RANGE(128, 8, 4);
+#define FDR_LAUNCH_RANGE_PP(DP_)                                                                        \
+    do {                                                                                                \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_range_pp_kernel<DP_, 8>),         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));            \
+        hipLaunchKernelGGL((knn_range_pp_kernel<DP_, 8>), dim3((unsigned)rp.nqb, (unsigned)rp.nseg), dim3(512), rlds, \
+                           st, (const _Float16 *)d_hqc, (const float *)d_thetac, c, (const _Float16 *)d_ht, (int)nt,  \
+                           (int)t_base, rp.segs, d_cnt, d_rcand);                                       \
+    } while (0)
+            if (use_pp && dp == 128) FDR_LAUNCH_RANGE_PP(128);
+            else if (use_pp && dp == 256) FDR_LAUNCH_RANGE_PP(256);
+            else if (use_pp) FDR_LAUNCH_RANGE_PP(512);
+            else if (wide) FDR_LAUNCH_RANGE(128, 8, 4);
             else if (dp == 128) FDR_LAUNCH_RANGE(128, 4, 4);
             else if (dp == 256) FDR_LAUNCH_RANGE(256, 4, 2);
             else FDR_LAUNCH_RANGE(512, 4, 2);
 #undef FDR_LAUNCH_RANGE
+#undef FDR_LAUNCH_RANGE_PP
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(knn_rerank_long_kernel, dim3((unsigned)((c + 3) / 4)), dim3(256), 0, st,
                                (const int *)(d_rlist + first), c, (const int *)d_cnt, (const int *)d_rcand, k,
@@ -1552,7 +1576,8 @@ static int upload_embed_pipelined(fdr_ctx *ctx, int64_t n_rows, const int64_t *a
         return launch_embed(ctx, n_rows, (const int64_t *)ctx->a_indptr.p, (const int32_t *)ctx->a_indices.p, d_E, ctx->stream);
     }
     // chunks of ~T ids, cut at row boundaries by bisection of the (monotone) row pointers
-    const int64_t T = std::max<int64_t>(1 << 18, std::min<int64_t>(1 << 21, nnz / 64));
+    const int64_t T = 1 << 18;  // (1 MB of ids: ~0.25 ms for a helper, 18 us on the link; helpers' chunks cost no launch each)
+    const int RUN = 8;          // chunks the link takes at once
     std::vector<hup::Chunk> chunks;
     for (int64_t r = 0; r < n_rows;) {
         const int64_t want = a_indptr[r] + T;
@@ -1584,58 +1609,80 @@ static int upload_embed_pipelined(fdr_ctx *ctx, int64_t n_rows, const int64_t *a
 
     // the two fronts: chunks [front, back) are unclaimed
     std::atomic<uint64_t> ends{(uint64_t)nch};  // front << 32 | back
-    auto claim = [&](bool from_back) -> int64_t {
+    auto claim = [&](bool from_back, int want, int &got) -> int64_t {  // up to `want` chunks from one end; returns the first
         uint64_t v = ends.load();
         for (;;) {
             const uint64_t f = v >> 32, b = v & 0xffffffffull;
             if (f >= b) return -1;
-            const uint64_t nv = from_back ? (f << 32 | (b - 1)) : ((f + 1) << 32 | b);
-            if (ends.compare_exchange_weak(v, nv)) return (int64_t)(from_back ? b - 1 : f);
+            const uint64_t m = std::min<uint64_t>((uint64_t)want, b - f);
+            const uint64_t nv = from_back ? (f << 32 | (b - m)) : ((f + m) << 32 | b);
+            if (ends.compare_exchange_weak(v, nv)) {
+                got = (int)m;
+                return (int64_t)(from_back ? b - m : f);
+            }
         }
     };
-    std::atomic<int64_t> stage_used{0};
-    std::atomic<bool> stage_full{false};
+    // The helpers' chunks end up in ROW ORDER at the END of the staging buffer, without gaps -- chunk ci right below
+    // chunk ci + 1 -- so that what they produced is one copy of ids, one of row pointers and ONE embed launch, however
+    // small the chunks.  A helper that has compacted chunk ci (into a buffer of its own) waits for cum[ci + 1], the ids
+    // of all chunks above it (a chained scan: that chunk was claimed just before this one and takes as long), publishes
+    // cum[ci] and copies its ids to stage_ids + stage_cap - cum[ci]; its rows' pointers are absolute positions there.
+    std::vector<std::atomic<int64_t>> cum((size_t)nch + 1);
+    for (auto &c : cum) c.store(-1, std::memory_order_relaxed);
+    cum[(size_t)nch].store(0);
+    std::atomic<bool> overflow{false};
     std::atomic<int64_t> bad_row{-1};
     const uint32_t *bw = ctx->h_bits.data();
     const uint64_t F = (uint64_t)ctx->n_features;
     auto worker = [&]() {
         std::vector<int32_t> scratch;
-        while (!stage_full.load()) {
-            const int64_t ci = claim(true);
+        std::vector<int64_t> lptr;
+        for (;;) {
+            int got = 0;
+            const int64_t ci = claim(true, 1, got);
             if (ci < 0) break;
             hup::Chunk &c = chunks[(size_t)ci];
-            const int64_t raw = a_indptr[c.r1] - a_indptr[c.r0];
-            for (int64_t r = c.r0; r < c.r1; ++r)
+            const int64_t raw = a_indptr[c.r1] - a_indptr[c.r0], rows = c.r1 - c.r0;
+            int64_t n = 0;
+            bool ok = !overflow.load() && bad_row.load() < 0;
+            for (int64_t r = c.r0; ok && r < c.r1; ++r)
                 if (a_indptr[r + 1] < a_indptr[r]) {
                     int64_t exp = -1;
                     bad_row.compare_exchange_strong(exp, r);
+                    ok = false;
                 }
-            if (bad_row.load() >= 0) break;
-            if ((int64_t)scratch.size() < raw + 16) scratch.resize((size_t)raw + 16);  // (+ 16: the vector loop stores whole registers)
-            int64_t *ptr = stage_ptr + c.r0 + ci;  // (chunk ci's rows + 1 pointers: disjoint from every other chunk's)
-            const int64_t n = csrc::compact_chunk(bw, F, a_indptr, a_indices, c.r0, c.r1, scratch.data(), raw, ptr);
-            const int64_t off = stage_used.fetch_add(n);
-            if (off + n > stage_cap) {  // (P keeps far more ids than expected: this chunk and the rest go raw)
-                stage_full.store(true);
-                c.staged_off = -2;
-                break;
+            if (ok) {
+                if ((int64_t)scratch.size() < raw + 16) scratch.resize((size_t)raw + 16);  // (+ 16: the vector loop stores whole registers)
+                if ((int64_t)lptr.size() < rows + 1) lptr.resize((size_t)rows + 1);
+                n = csrc::compact_chunk(bw, F, a_indptr, a_indices, c.r0, c.r1, scratch.data(), raw, lptr.data());
             }
-            memcpy(stage_ids + off, scratch.data(), (size_t)n * 4);
-            c.staged_off = off;
+            int64_t above;  // (every claimed chunk publishes, whatever happened to it: the chain must not break)
+            while ((above = cum[(size_t)ci + 1].load(std::memory_order_acquire)) < 0) std::this_thread::yield();
+            const int64_t mine = above + (ok ? n : 0);
+            if (ok && mine > stage_cap) {  // (P keeps far more ids than expected: the helpers' chunks go raw after all)
+                overflow.store(true);
+                ok = false;
+            }
+            cum[(size_t)ci].store(ok ? mine : above, std::memory_order_release);
+            if (!ok) {
+                c.staged_off = -2;
+                continue;
+            }
+            const int64_t base = stage_cap - mine;
+            memcpy(stage_ids + base, scratch.data(), (size_t)n * 4);
+            for (int64_t r = 0; r < rows; ++r) stage_ptr[c.r0 + r] = base + lptr[(size_t)r];
+            c.staged_off = base;
             c.staged_n = n;
         }
     };
-    std::vector<std::thread> pool;
-    try {
-        for (int t = 0; t < nthr; ++t) pool.emplace_back(worker);
-    } catch (...) {  // (fewer helpers than hoped: the link carries more)
-    }
-    auto send_raw = [&](const hup::Chunk &c, int slot) -> int {
-        const int64_t o = a_indptr[c.r0], len = a_indptr[c.r1] - o;
+    ctx->up_pool.ensure(nthr);  // (fewer helpers than hoped: the link carries more)
+    ctx->up_pool.start(worker);
+    auto send_raw = [&](int64_t r0, int64_t r1, int slot) -> int {  // rows [r0, r1) as they are, the embed kernel behind them
+        const int64_t o = a_indptr[r0], len = a_indptr[r1] - o;
         if (len > 0)
             HIP_TRY(hipMemcpyAsync((int32_t *)ctx->a_indices.p + o, a_indices + o, (size_t)len * 4, hipMemcpyHostToDevice, st));
-        int erc = launch_embed(ctx, c.r1 - c.r0, (const int64_t *)ctx->a_indptr.p + c.r0, (const int32_t *)ctx->a_indices.p,
-                               d_E + (size_t)c.r0 * d, st);
+        int erc = launch_embed(ctx, r1 - r0, (const int64_t *)ctx->a_indptr.p + r0, (const int32_t *)ctx->a_indices.p,
+                               d_E + (size_t)r0 * d, st);
         if (erc) return erc;
         if (slot >= 0) HIP_TRY(hipEventRecord(ctx->up_ev[slot], st));
         return FDR_OK;
@@ -1643,46 +1690,40 @@ static int upload_embed_pipelined(fdr_ctx *ctx, int64_t n_rows, const int64_t *a
     int urc = FDR_OK;
     int64_t sent = 0;
     for (; urc == FDR_OK; ++sent) {
-        if (sent >= 2) {  // two chunks in flight: the next is claimed when the link has taken the one before the last
+        if (sent >= 2) {  // two runs in flight: the next is claimed when the link has taken the one before the last
             hipError_t e = hipEventSynchronize(ctx->up_ev[sent & 1]);
             if (e != hipSuccess) {
                 urc = fail(FDR_E_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(e));
                 break;
             }
         }
-        const int64_t ci = claim(false);
+        int got = 0;
+        const int64_t ci = claim(false, RUN, got);
         if (ci < 0) break;
-        urc = send_raw(chunks[(size_t)ci], (int)(sent & 1));
+        urc = send_raw(chunks[(size_t)ci].r0, chunks[(size_t)(ci + got - 1)].r1, (int)(sent & 1));
     }
-    for (std::thread &t : pool) t.join();
+    ctx->up_pool.wait();
     if (urc) return urc;
     if (bad_row.load() >= 0) return fail(FDR_E_ARG, "embed: indptr not monotone at row %lld", (long long)bad_row.load());
-    // what the helpers left: chunks they could not stage go raw; the staged ids and row pointers follow in two copies
-    const int64_t used = std::min<int64_t>(stage_used.load(), stage_cap);
-    bool any_staged = false;
-    for (int64_t ci = 0; ci < nch; ++ci) {
-        hup::Chunk &c = chunks[(size_t)ci];
-        const uint64_t v = ends.load();
-        const bool claimed = (uint64_t)ci < (v >> 32) || (uint64_t)ci >= (v & 0xffffffffull);
-        if (c.staged_off >= 0) any_staged = true;
-        else if (c.staged_off == -2 || !claimed) {  // dropped by a helper, or never claimed (helpers stopped early)
-            if ((rc = send_raw(c, -1))) return rc;
-        }
-    }
-    if (any_staged) {
-        if (used > 0)
-            HIP_TRY(hipMemcpyAsync(ctx->c_indices.p, stage_ids, (size_t)used * 4, hipMemcpyHostToDevice, st));
-        // (the pointers of the staged chunks only: they lie at the back, from the first staged chunk's slot on)
-        int64_t first = nch;
-        for (int64_t ci = 0; ci < nch; ++ci)
-            if (chunks[(size_t)ci].staged_off >= 0) { first = ci; break; }
-        const int64_t p0 = chunks[(size_t)first].r0 + first, p1 = n_rows + nch;
-        HIP_TRY(hipMemcpyAsync((int64_t *)ctx->c_indptr.p + p0, stage_ptr + p0, (size_t)(p1 - p0) * 8, hipMemcpyHostToDevice, st));
-        for (int64_t ci = first; ci < nch; ++ci) {
-            const hup::Chunk &c = chunks[(size_t)ci];
-            if (c.staged_off < 0) continue;
-            if ((rc = launch_embed(ctx, c.r1 - c.r0, (const int64_t *)ctx->c_indptr.p + c.r0 + ci,
-                                   (const int32_t *)ctx->c_indices.p + c.staged_off, d_E + (size_t)c.r0 * d, st)))
+    // what the helpers left: chunks [first, nch), in row order at the end of the staging buffer -- two copies and one
+    // launch; if the staging buffer overflowed (a dense P) or a chunk was dropped, their rows go raw after all
+    const int64_t first = (int64_t)(ends.load() & 0xffffffffull);  // (the helpers claimed downwards from nch)
+    if (first < nch) {
+        bool all_staged = !overflow.load();
+        for (int64_t ci = first; ci < nch && all_staged; ++ci) all_staged = chunks[(size_t)ci].staged_off >= 0;
+        const int64_t rb = chunks[(size_t)first].r0;
+        if (!all_staged) {
+            if ((rc = send_raw(rb, n_rows, -1))) return rc;
+        } else {
+            const int64_t used = cum[(size_t)first].load();
+            stage_ptr[n_rows] = stage_cap;
+            if (used > 0)
+                HIP_TRY(hipMemcpyAsync((int32_t *)ctx->c_indices.p + (stage_cap - used), stage_ids + (stage_cap - used),
+                                       (size_t)used * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((int64_t *)ctx->c_indptr.p + rb, stage_ptr + rb, (size_t)(n_rows - rb + 1) * 8,
+                                   hipMemcpyHostToDevice, st));
+            if ((rc = launch_embed(ctx, n_rows - rb, (const int64_t *)ctx->c_indptr.p + rb, (const int32_t *)ctx->c_indices.p,
+                                   d_E + (size_t)rb * d, st)))
                 return rc;
         }
     }

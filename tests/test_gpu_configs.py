@@ -131,7 +131,8 @@ def test_per_rank_workspace_of_configs_4_and_5_fits_hbm(ctx):
     (2.5 M x 20 M, d = 256, k = 50), plus the gathered embeddings and the results, against 288 GB of HBM."""
     hbm = ctx.device_info()["hbm_bytes"]
     assert hbm > 250e9
-    for nq, nt, d, k in ((1_250_000, 10_000_000, 128, 20), (2_500_000, 20_000_000, 256, 50)):
+    # ... and config 4's whole matrix on ONE GPU (10 M x 10 M: the N = 1 point of its scaling curve, profiles/r4_bench_10m.json)
+    for nq, nt, d, k in ((1_250_000, 10_000_000, 128, 20), (2_500_000, 20_000_000, 256, 50), (10_000_000, 10_000_000, 128, 20)):
         ws = ctx.knn_workspace_bytes(nq, nt, d, k)
         total = ws + nt * ctx.padded_dim(d) * 4 + nt + nq * k * 8
         assert 0 < ws and total < 0.9 * hbm, (nq, nt, d, k, ws, total)
