@@ -739,9 +739,9 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
 // build all of them (the round-3 shapes the knobs D256 / PP can put back), or a subset to save minutes of hipcc.
 #ifndef FDR_SHAPE_MASK
 #ifdef FDR_DEV
-#define FDR_SHAPE_MASK 0x7fff
+#define FDR_SHAPE_MASK 0xffff
 #else
-#define FDR_SHAPE_MASK 0x24CF  // the shapes prefilter_shape() can choose without a development knob: cases 0-3, 6, 7, 10, 13
+#define FDR_SHAPE_MASK 0xA4CE  // the shapes prefilter_shape() can choose without a development knob: cases 1-3, 6, 7, 10, 13, 15
 #endif
 #endif
 #ifndef FDR_LH_MASK
@@ -825,6 +825,11 @@ static int launch_knn_exact(fdr_ctx *ctx, const float *d_Qhat, const uint8_t *d_
 #define FDR_SHAPE_ON_14 1
 #else
 #define FDR_SHAPE_ON_14 0
+#endif
+#if (FDR_SHAPE_MASK >> 15) & 1
+#define FDR_SHAPE_ON_15 1
+#else
+#define FDR_SHAPE_ON_15 0
 #endif
 #if FDR_LH_MASK & 16
 #define FDR_LH_ON_16 1
@@ -974,7 +979,8 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
         if (dp == 128 && kp <= 32) {
             // d <= 128, K' <= 32: the stage's two tiles as two interleaved MFMA chains (1-4 % faster; still
             // <= 128 VGPRs)
-            if (sh.nw == 8) FDR_SHAPE_CASE(0, FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512));
+            if (sh.nw == 8 && sh.tps == 8) FDR_SHAPE_CASE(15, FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 4, 16, true>), 512));
+            else if (sh.nw == 8) FDR_SHAPE_CASE(0, FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 8, 4, 2, 16, true>), 512));
             else FDR_SHAPE_CASE(1, FDR_LAUNCH_PRE3((knn_prefilter_kernel<128, 1, 4, 4, 2, 16, true>), 256));
         } else if (dp == 128) FDR_SHAPE_CASE(2, FDR_LAUNCH_PRE(128, 1, 4, 4, 2));
         else if (sh.nw == 8 && sh.wps == 2 && (sh.tps == 16 || (dp == 512 && sh.tps == 8)) && dev_knobs().pp != 0) {
