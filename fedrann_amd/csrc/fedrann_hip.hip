@@ -70,47 +70,63 @@ __global__ __launch_bounds__(256) void embed_csr_kernel(
     long long n_features, const uint2 *__restrict__ ftab, const uint4 *__restrict__ rowinfo,
     const uint2 *__restrict__ ent, int d, float *__restrict__ E) {
     constexpr int NACC = DP / 64;
-    constexpr int NB = 4;  // 64-id chunks in flight per wave
+    constexpr int NB = 4;   // 64-id chunks in flight per wave and row
+    constexpr int RPW = 2;  // rows a wave has in flight: the id -> bitmap -> rowinfo chain is three dependent loads (~2 us a
+                            // row), and the occupancy that hides it is all there is -- two rows' chains side by side
     const int lane = threadIdx.x & 63;
     const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-    for (long long row = wave0; row < n_rows; row += nwaves) {
-        float acc[NACC];
+    for (long long row0 = wave0 * RPW; row0 < n_rows; row0 += nwaves * RPW) {
+        long long beg[RPW], end[RPW];
+        int f[RPW][NB];
+        uint2 w[RPW][NB];
+        uint4 info[RPW][NB];
+        bool hit[RPW][NB];
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
-        const long long beg = a_indptr[row], end = a_indptr[row + 1];
-        for (long long base = beg; base < end; base += 64 * NB) {
-            int f[NB];
+        for (int r = 0; r < RPW; ++r) {
+            const long long row = row0 + r < n_rows ? row0 + r : n_rows - 1;
+            beg[r] = a_indptr[row];
+            end[r] = row0 + r < n_rows ? a_indptr[row + 1] : beg[r];
+        }
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const long long pos = base + 64 * u + lane;
-                f[u] = pos < end ? a_indices[pos] : -1;
-            }
-            uint2 w[NB];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                w[u] = make_uint2(0u, 0u);
-                if (f[u] >= 0 && (long long)f[u] < n_features) w[u] = ftab[f[u] >> 5];
-            }
-            uint4 info[NB];
-            bool hit[NB];
+        for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const unsigned bit = 1u << (f[u] & 31);
-                hit[u] = (w[u].x & bit) != 0u;
-                info[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (hit[u]) info[u] = rowinfo[w[u].y + __popc(w[u].x & (bit - 1u))];
+                const long long pos = beg[r] + 64 * u + lane;
+                f[r][u] = pos < end[r] ? a_indices[pos] : -1;
             }
 #pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
             for (int u = 0; u < NB; ++u) {
-                u64 m = __ballot(hit[u]);
-                while (m) {  // wave-uniform: hits in ascending lane = ascending feature order
+                w[r][u] = make_uint2(0u, 0u);
+                if (f[r][u] >= 0 && (long long)f[r][u] < n_features) w[r][u] = ftab[f[r][u] >> 5];
+            }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const unsigned bit = 1u << (f[r][u] & 31);
+                hit[r][u] = (w[r][u].x & bit) != 0u;
+                info[r][u] = make_uint4(0u, 0u, 0u, 0u);
+                if (hit[r][u]) info[r][u] = rowinfo[w[r][u].y + __popc(w[r][u].x & (bit - 1u))];
+            }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            if (row0 + r >= n_rows) break;  // (wave-uniform)
+            float acc[NACC];
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+            // hits in ascending lane = ascending feature order, applied by the whole wave (lane l owns columns l, l + 64, ...)
+            auto apply = [&](const uint4 &inf, const bool h) {
+                u64 m = __ballot(h);
+                while (m) {  // wave-uniform
                     const int src = __builtin_ctzll(m);
                     m &= m - 1;
-                    int q = __builtin_amdgcn_readlane((int)info[u].x, src);
-                    const int ee = q + __builtin_amdgcn_readlane((int)info[u].y, src);
-                    unsigned c = (unsigned)__builtin_amdgcn_readlane((int)info[u].z, src);
-                    float v = __int_as_float(__builtin_amdgcn_readlane((int)info[u].w, src));
+                    int q = __builtin_amdgcn_readlane((int)inf.x, src);
+                    const int ee = q + __builtin_amdgcn_readlane((int)inf.y, src);
+                    unsigned c = (unsigned)__builtin_amdgcn_readlane((int)inf.z, src);
+                    float v = __int_as_float(__builtin_amdgcn_readlane((int)inf.w, src));
                     while (true) {
 #pragma unroll
                         for (int i = 0; i < NACC; ++i)
@@ -121,12 +137,37 @@ __global__ __launch_bounds__(256) void embed_csr_kernel(
                         v = __uint_as_float(en.y);
                     }
                 }
-            }
-        }
-        float *out = E + row * (long long)d;
+            };
 #pragma unroll
-        for (int i = 0; i < NACC; ++i)
-            if (lane + 64 * i < d) out[lane + 64 * i] = acc[i];
+            for (int u = 0; u < NB; ++u) apply(info[r][u], hit[r][u]);
+            // rows longer than the 256 ids in flight (the full CSR of a long read): the rest, chunk by chunk
+            for (long long base = beg[r] + 64 * NB; base < end[r]; base += 64 * NB) {
+                int f2[NB];
+                uint2 w2[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const long long pos = base + 64 * u + lane;
+                    f2[u] = pos < end[r] ? a_indices[pos] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    w2[u] = make_uint2(0u, 0u);
+                    if (f2[u] >= 0 && (long long)f2[u] < n_features) w2[u] = ftab[f2[u] >> 5];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const unsigned bit = 1u << (f2[u] & 31);
+                    const bool h2 = (w2[u].x & bit) != 0u;
+                    uint4 i2 = make_uint4(0u, 0u, 0u, 0u);
+                    if (h2) i2 = rowinfo[w2[u].y + __popc(w2[u].x & (bit - 1u))];
+                    apply(i2, h2);
+                }
+            }
+            float *out = E + (row0 + r) * (long long)d;
+#pragma unroll
+            for (int i = 0; i < NACC; ++i)
+                if (lane + 64 * i < d) out[lane + 64 * i] = acc[i];
+        }
     }
 }
 
@@ -500,7 +541,7 @@ static int launch_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *d_indptr,
     if (n_rows < 0) return fail(FDR_E_ARG, "embed: n_rows < 0");
     if (n_rows == 0) return FDR_OK;
     const int dp = fdr_padded_dim(ctx->d);
-    const long long blocks_needed = (n_rows + 3) / 4;
+    const long long blocks_needed = (n_rows + 7) / 8;  // (four waves per block, two rows per wave and turn)
     const int grid = (int)std::min<long long>(blocks_needed, (long long)ctx->num_cus * 8 * 4);
     int trc = timing_begin(ctx, FDR_KERNEL_EMBED, st);
     if (trc) return trc;
