@@ -19,7 +19,7 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 oracle.lib()
 ctx = _lib.Context(0)
 kw = dict(d=128, k=20, doubling=False) if cfg == 4 else dict(d=256, k=50, doubling=True, sample=64)
-info = run_rank_share(ctx, oracle, R=R, ranks=G, reps=reps,
+info = run_rank_share(ctx, oracle, R=R, ranks=G, reps=reps, unique_split=True,
                       log=lambda *a: print("[config%d]" % cfg, *a, file=sys.stderr, flush=True), **kw)
 info["device"] = ctx.device_info()
 print(json.dumps(info))

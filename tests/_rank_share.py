@@ -30,7 +30,7 @@ def host_threads(per_thread_gb=3.0):
 
 
 def run_rank_share(ctx, oracle, R, d, k, doubling, ranks=8, rank=0, sample=64, piece_reads=1_600_000, seed=602,
-                   reps=1, log=None):
+                   reps=1, log=None, unique_split=False):
     import torch
     from fedrann_amd.distributed import HipEngine, shard_rows
     from fedrann_amd.precompute import build_precompute_matrix
@@ -134,6 +134,7 @@ def run_rank_share(ctx, oracle, R, d, k, doubling, ranks=8, rank=0, sample=64, p
                 prefilter_pflops_on_unique_rows=(2.0 * ut * uq * d / (info["kernels_ms"]["knn_prefilter"] * 1e-3) / 1e15
                                                  if info["kernels_ms"].get("knn_prefilter") else None))
     paths = ctx.last_query_paths(nq)  # (before the workspace is used again)
+    idx_keep, dst_keep = idx.clone(), dst.clone()
     # rows of the block that share their normalised row, bit for bit, with another row of the matrix -- counted
     # independently of the library (a 64-bit hash of the row's bits, torch on the device)
     g = torch.Generator(device=dev)
@@ -145,9 +146,34 @@ def run_rank_share(ctx, oracle, R, d, k, doubling, ranks=8, rank=0, sample=64, p
         hsh[c0:c1] = (Ehat[c0:c1].view(torch.int32).to(torch.int64) * w).sum(1)
     _, inv, mult = torch.unique(hsh, return_inverse=True, return_counts=True)
     members_expected = int((mult[inv[lo:hi]] > 1).sum().item())
-    del Ehat, hsh, inv, mult
-    idx_h, dst_h = idx.cpu().numpy(), dst.cpu().numpy()
-    del idx, dst
+    del hsh, inv, mult
+    # ---- what the rank does in distributed.ShardedPipeline when the rows repeat: classes of all rows, k-NN of ITS SHARE
+    # of the unique rows (1 / ranks of them, not the unique rows of its block), expansion after the exchange -- timed
+    # here without the exchange; its share's rows that are also unique rows of the block must equal the direct result
+    if unique_split:
+        nq_max = -(-n // ranks)
+        nu = eng.knn_classes(Ehat, zero, n, d, k, nq_max)
+        if nu > 0:
+            Su = -(-nu // ranks)
+            iu = torch.zeros((Su, k), dtype=torch.int32, device=dev)
+            du = torch.zeros((Su, k), dtype=torch.float32, device=dev)
+            best2 = None
+            for rep in range(max(1, reps)):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                eng.knn_classes(Ehat, zero, n, d, k, nq_max)
+                eng.knn_unique(rank * Su, min(nu, (rank + 1) * Su), k, iu, du)
+                torch.cuda.synchronize(dev)
+                sec2 = time.perf_counter() - t0
+                best2 = sec2 if best2 is None else min(best2, sec2)
+            info.update(unique_rows=int(nu), unique_rows_per_rank=int(min(nu, (rank + 1) * Su) - rank * Su),
+                        unique_split_seconds=best2,
+                        node_read_pairs_per_s_unique_split=n * k / best2)
+            say("unique-row split: %d of %d unique rows, classes + k-NN %.3f s" % (info["unique_rows_per_rank"], nu, best2))
+            del iu, du
+    del Ehat
+    idx_h, dst_h = idx_keep.cpu().numpy(), dst_keep.cpu().numpy()
+    del idx, dst, idx_keep, dst_keep
 
     # ---- whole-result properties ----------------------------------------------------------------------------
     key = dst_h.view(np.uint32).astype(np.uint64) << np.uint64(32) | idx_h.astype(np.uint64)
