@@ -126,6 +126,22 @@ def test_reference_default_dimension_500_in_rounds(ctx, oracle):
     assert ctx.last_prefilter_launches()[1] == 2
 
 
+def test_ping_pong_kernel_short_lists_d256_and_d500(ctx, oracle):
+    """The ping-pong candidate pass with 2 x 16-key register lists (K' <= 32: k = 20), which no BASELINE config runs:
+    d = 256 (knn_prefilter_pp_kernel<256, 8, 16>) on 200 k rows all pairs, d = 500 (<512, 8, 16>: eight-unit stages,
+    two tiles of accumulators) on a rank's quarter of 600 k rows -- 512 query blocks and more, so that prefilter_shape()
+    chooses it; sparse rows with exact duplicates and all-zero rows."""
+    ctx.set_knn_mode("auto")
+    ctx.set_dedup_mode("auto")
+    E = _device_embeddings(400_000, 256, nnz=8, loci=150_000, seed=8, doubling=True)
+    _check_rank_share(ctx, oracle, E[:200_000].contiguous(), 200_000, 20, sample=128)
+    assert ctx.last_prefilter_launches()[1] == 2  # (launches of one workgroup per CU on two queues)
+    del E
+    E = _device_embeddings(600_000, 500, nnz=8, loci=250_000, seed=9)
+    _check_rank_share(ctx, oracle, E, 150_000, 20, sample=128)
+    assert ctx.last_prefilter_launches()[1] == 2
+
+
 def test_per_rank_workspace_of_configs_4_and_5_fits_hbm(ctx):
     """fdr_knn_workspace_bytes for one rank of config 4 (1.25 M x 10 M, d = 128, k = 20) and of config 5
     (2.5 M x 20 M, d = 256, k = 50), plus the gathered embeddings and the results, against 288 GB of HBM."""
