@@ -1029,9 +1029,6 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
             if (dp == 256) {
                 if (kp <= 32) FDR_SHAPE_CASE(3, FDR_LH_CASE(16, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<256, 8, 16>), 512)));
                 else FDR_SHAPE_CASE(3, FDR_LH_CASE(32, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<256, 8, 32>), 512)));
-            } else if (dp == 128) {  // (development: PP = 1)
-                if (kp <= 32) FDR_SHAPE_CASE(12, FDR_LH_CASE(16, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<128, 8, 16>), 512)));
-                else FDR_SHAPE_CASE(12, FDR_LH_CASE(32, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<128, 4, 32>), 512)));
             } else if (dp == 512 && sh.tps == 16 && kp <= 32) {
                 FDR_SHAPE_CASE(13, FDR_LH_CASE(16, FDR_LAUNCH_PRE3((knn_prefilter_pp_kernel<512, 8, 16>), 512)));
             } else if (dp == 512 && sh.tps == 8 && kp > 32) {
