@@ -629,9 +629,10 @@ static PrefilterLayout prefilter_layout(const fdr_ctx *ctx, int64_t nq, int64_t 
     L.chunk = (int)std::min<int64_t>(nq, 16384);
     const size_t exact_all = knn_plan(ctx->num_cus, nq, nt, d, k).total_bytes;
     const int dp = fdr_padded_dim(d);
-    const KnnPlan pp = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp, nq, ctx->num_cus));
+    const KnnPlan pp = knn_plan(ctx->num_cus, nq, nt, d, L.kp, prefilter_shape(dp, L.kp, nq, ctx->num_cus, nt));
     // (a later call on fewer unique rows may plan more, shorter segments: room for the largest such plan)
-    const size_t pre = std::max(pp.total_bytes, pp.bits_bytes + pp.shared_bytes +
+    // (the bound words and the lists padded for the widest query block: a later call may choose the other shape)
+    const size_t pre = std::max(pp.total_bytes, pp.bits_bytes + align256((size_t)(nq + 512) * 4) +
                                                     prefilter_partial_bound(nq, nt, L.kp, pp.qw));
     // any exact plan for <= chunk queries: bits + bound words + at most FDR_MAX_SEG segments of lists
     const size_t chunk_bound = align256((size_t)((nt + 31) / 32) * 4) + align256((size_t)(L.chunk + 128) * 4) +
@@ -911,7 +912,7 @@ static int launch_knn_prefilter(fdr_ctx *ctx, const float *d_Qhat, const uint8_t
     ctx->paths.stream = st;
 
     const int dp = fdr_padded_dim(d);
-    const int pshape = prefilter_shape(dp, kp, nq, ctx->num_cus);
+    const int pshape = prefilter_shape(dp, kp, nq, ctx->num_cus, nt);
     const KnnPlan p = knn_plan(ctx->num_cus, nq, nt, d, kp, pshape);
     const KnnShape &sh = kShapes[pshape];
     unsigned *d_bits = reinterpret_cast<unsigned *>(ws);
