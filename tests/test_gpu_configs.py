@@ -142,6 +142,19 @@ def test_ping_pong_kernel_short_lists_d256_and_d500(ctx, oracle):
     assert ctx.last_prefilter_launches()[1] == 2
 
 
+def test_rank_slice_of_one_million_rows_d128_in_one_launch(ctx, oracle):
+    """One rank's share of 1 M rows at d = 128 / k = 20 (the bench default on eight or nine GPUs): between one and 1.8 query blocks
+    per workgroup slot and >= 4 targets per query, where prefilter_shape() takes the eight-wave four-stage pass in ONE
+    launch of guided segments -- a combination neither the all-pairs cases (rounds, or the four-wave shape) nor
+    config 4's share (rounds) run."""
+    ctx.set_knn_mode("auto")
+    ctx.set_dedup_mode("auto")
+    E = _device_embeddings(1_000_000, 128, nnz=8, loci=400_000, seed=11)
+    ut, uq = _check_rank_share(ctx, oracle, E, 110_000, 20, sample=192)  # (a ninth: 430 query blocks of 256)
+    assert 65_536 <= uq <= 117_900 and ut >= 4 * uq  # (256 .. 460 blocks of 256 unique queries on 256 CUs)
+    assert ctx.last_prefilter_launches() == (1, 1)
+
+
 def test_per_rank_workspace_of_configs_4_and_5_fits_hbm(ctx):
     """fdr_knn_workspace_bytes for one rank of config 4 (1.25 M x 10 M, d = 128, k = 20) and of config 5
     (2.5 M x 20 M, d = 256, k = 50), plus the gathered embeddings and the results, against 288 GB of HBM."""
