@@ -211,6 +211,9 @@ def cpu_baseline(s, P, d, k, target_seconds, gpu_result=None):
 
 def main():
     args = parse_args()
+    # (multi-process GPU work on this pool needs dmabuf IPC: RCCL fails with hipIpcGetMemHandle otherwise; exported by the
+    # image already, kept here for environments that drop it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -395,6 +395,7 @@ def launch_rank_workers(argv, args, devices, output_dir, temp_dir, keep_intermed
     for rank, dev in enumerate(devices):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(len(devices)), LOCAL_RANK=str(rank),
                    FEDRANN_DEVICE=str(dev), FEDRANN_RENDEZVOUS=rendezvous)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL between processes needs dmabuf IPC on hosts like this pool's)
         procs.append(subprocess.Popen([sys.executable, "-m", "fedrann_amd"] + argv + ["--rank-worker"], env=env))
     # poll all ranks: the first failure ends the others (they would sit in a collective until its timeout); whatever ends
     # the parent -- KeyboardInterrupt, SIGTERM turned into SystemExit, an error here -- ends the ranks and removes the
