@@ -181,20 +181,37 @@ __global__ __launch_bounds__(256) void embed_csr_kernel(
 // [k0 k2 k4 k6 | k1 k3 k5 k7] so that lane-half h of the MFMA reads its four K-steps
 // (components 8g + 2s + h, s = 0..3) as ONE 16-byte access.
 // ------------------------------------------------------------------------------------------
-template <int DP, int RB>
-__global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restrict__ E,
-                                                            long long n_rows, int d,
-                                                            float *__restrict__ Ehat,
-                                                            unsigned char *__restrict__ zero) {
+template <int DP, int RB, bool VEC>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float *__restrict__ E,
+                                                             long long n_rows, int d,
+                                                             float *__restrict__ Ehat,
+                                                             unsigned char *__restrict__ zero) {
+    // 256 threads move the RB rows in and out (VEC: 16 bytes per lane and access -- d a multiple of 4, both bases 16-byte
+    // aligned: 32 instead of 128 dependent-latency round trips per row block, four waves of them instead of one), the first
+    // RB threads run the rows' chains.
     __shared__ float tile[RB][DP + 1];  // +1: the per-lane row walk below is bank-conflict free
     const int tid = threadIdx.x;
     const long long row0 = (long long)blockIdx.x * RB;
     const int nr = (int)min((long long)RB, n_rows - row0);
     const float *src = E + row0 * (long long)d;
-    for (int i = tid; i < RB * DP; i += 64) tile[i / DP][i % DP] = 0.0f;
-    __syncthreads();
+    if (d < DP || nr < RB) {
+        for (int i = tid; i < RB * DP; i += 256) tile[i / DP][i % DP] = 0.0f;
+        __syncthreads();
+    }
     const int total = nr * d;
-    for (int i = tid; i < total; i += 64) tile[i / d][i % d] = src[i];
+    if constexpr (VEC) {
+        const f32x4 *src4 = reinterpret_cast<const f32x4 *>(src);
+        for (int i4 = tid; i4 < total / 4; i4 += 256) {
+            const f32x4 v = src4[i4];
+            const int i = 4 * i4, r = i / d, c = i - r * d;  // (d % 4 == 0: the four stay in one row)
+            tile[r][c] = v[0];
+            tile[r][c + 1] = v[1];
+            tile[r][c + 2] = v[2];
+            tile[r][c + 3] = v[3];
+        }
+    } else {
+        for (int i = tid; i < total; i += 256) tile[i / d][i % d] = src[i];
+    }
     __syncthreads();
     if (tid < RB) {
         float n = 0.0f;
@@ -211,10 +228,20 @@ __global__ __launch_bounds__(64) void normalize_rows_kernel(const float *__restr
     }
     __syncthreads();
     float *dst = Ehat + row0 * (long long)DP;
-    for (int i = tid; i < nr * DP; i += 64) {
-        const int r = i / DP, p = i % DP;
-        const int g = p >> 3, hh = (p >> 2) & 1, s = p & 3;
-        dst[i] = tile[r][8 * g + 2 * s + hh];
+    if constexpr (VEC) {
+        f32x4 *dst4 = reinterpret_cast<f32x4 *>(dst);
+        for (int i4 = tid; i4 < nr * DP / 4; i4 += 256) {
+            const int i = 4 * i4, r = i / DP, p = i % DP;  // (p % 4 == 0: s = 0 .. 3 below)
+            const int g = p >> 3, hh = (p >> 2) & 1;
+            const float *t = &tile[r][8 * g + hh];
+            dst4[i4] = f32x4{t[0], t[2], t[4], t[6]};
+        }
+    } else {
+        for (int i = tid; i < nr * DP; i += 256) {
+            const int r = i / DP, p = i % DP;
+            const int g = p >> 3, hh = (p >> 2) & 1, s = p & 3;
+            dst[i] = tile[r][8 * g + 2 * s + hh];
+        }
     }
 }
 
@@ -576,21 +603,22 @@ static int launch_normalize(fdr_ctx *ctx, const float *d_E, int64_t n_rows, int 
     if (grid > 0x7fffffffll) return fail(FDR_E_ARG, "normalize: too many rows");
     int trc = timing_begin(ctx, FDR_KERNEL_NORMALIZE, st);
     if (trc) return trc;
-    if (dp == 128)
-        hipLaunchKernelGGL((normalize_rows_kernel<128, 64>), dim3((unsigned)grid), dim3(64), 0, st,
-                           d_E, (long long)n_rows, d, d_Ehat, d_zero);
-    else if (dp == 256)
-        hipLaunchKernelGGL((normalize_rows_kernel<256, 32>), dim3((unsigned)grid), dim3(64), 0, st,
-                           d_E, (long long)n_rows, d, d_Ehat, d_zero);
-    else if (dp == 512)
-        hipLaunchKernelGGL((normalize_rows_kernel<512, 16>), dim3((unsigned)grid), dim3(64), 0, st,
-                           d_E, (long long)n_rows, d, d_Ehat, d_zero);
-    else if (dp == 1024)
-        hipLaunchKernelGGL((normalize_rows_kernel<1024, 8>), dim3((unsigned)grid), dim3(64), 0, st,
-                           d_E, (long long)n_rows, d, d_Ehat, d_zero);
-    else
-        hipLaunchKernelGGL((normalize_rows_kernel<2048, 4>), dim3((unsigned)grid), dim3(64), 0, st,
-                           d_E, (long long)n_rows, d, d_Ehat, d_zero);
+    const bool vec = d % 4 == 0 && (reinterpret_cast<uintptr_t>(d_E) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_Ehat) & 15) == 0;
+#define FDR_LAUNCH_NORM(DP_, RB_)                                                                                  \
+    do {                                                                                                            \
+        if (vec)                                                                                                    \
+            hipLaunchKernelGGL((normalize_rows_kernel<DP_, RB_, true>), dim3((unsigned)grid), dim3(256), 0, st, d_E, \
+                               (long long)n_rows, d, d_Ehat, d_zero);                                              \
+        else                                                                                                        \
+            hipLaunchKernelGGL((normalize_rows_kernel<DP_, RB_, false>), dim3((unsigned)grid), dim3(256), 0, st,    \
+                               d_E, (long long)n_rows, d, d_Ehat, d_zero);                                         \
+    } while (0)
+    if (dp == 128) FDR_LAUNCH_NORM(128, 64);
+    else if (dp == 256) FDR_LAUNCH_NORM(256, 32);
+    else if (dp == 512) FDR_LAUNCH_NORM(512, 16);
+    else if (dp == 1024) FDR_LAUNCH_NORM(1024, 8);
+    else FDR_LAUNCH_NORM(2048, 4);
+#undef FDR_LAUNCH_NORM
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_NORMALIZE, st);
 }
