@@ -58,14 +58,174 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //                  prefix: number of non-empty rows among features < 32w }          (8 B / 32 features)
 //   rowinfo[r] = { start, count, first column, first value bits } of the r-th non-empty row  (16 B)
 //   ent[q]     = { column, fp32 bits }   (entries beyond a row's first)
-// A wave streams its row's column ids 256 at a time (four coalesced loads in flight), tests the
-// bitmap words (L2 resident) and fetches rowinfo for the hits, so a row pays the dependent
-// id -> bitmap -> rowinfo latency chain once per 256 non-zeros.  Hits are then applied in ascending
-// feature order by the whole wave (lane l owns columns l, l+64, ...), which reproduces scipy's
-// sequential fp32 sums bit for bit.
+// A wave streams a row's column ids in coalesced 64-id chunks, tests the bitmap words (L2 resident) and
+// fetches rowinfo for the hits; several rows' (short rows: eight, one chunk each) or chunks' (long rows: two
+// rows, four chunks each) dependent id -> bitmap -> rowinfo chains are in flight at once.  Hits are then
+// applied in ascending feature order by the whole wave (lane l owns columns l, l+64, ...), which reproduces
+// scipy's sequential fp32 sums bit for bit.
 // ------------------------------------------------------------------------------------------
 template <int DP>
 __global__ __launch_bounds__(256) void embed_csr_kernel(
+    long long n_rows, const long long *__restrict__ a_indptr, const int *__restrict__ a_indices,
+    long long n_features, const uint2 *__restrict__ ftab, const uint4 *__restrict__ rowinfo,
+    const uint2 *__restrict__ ent, int d, float *__restrict__ E) {
+    constexpr int NACC = DP / 64;
+    static_assert(DP <= 512, "d > 512: embed_csr_wide_kernel");
+    constexpr int GR = 8;   // rows a wave takes per turn
+    constexpr int NB = 4;   // long rows: 64-id chunks in flight per row
+    constexpr int RPW = 2;  // long rows: rows in flight
+    // The id -> bitmap -> rowinfo chain is three dependent loads (~2 us a row) and the rows in flight are all that hides
+    // it (stubbed lookups: the kernel's time does not depend on where rowinfo comes from, and the ordered application below
+    // is 18 % of it).  SHORT rows -- every row of a turn within 64 ids: a compacted CSR's ~17 live ids -- run eight chains
+    // side by side with one chunk each; LONG rows (a raw CSR's ~170 ids) two chains with four chunks each.
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    // hits in ascending lane = ascending feature order, applied by the whole wave (lane l owns columns l, l + 64, ...)
+    auto apply = [&](float (&acc)[NACC], const uint4 &inf, const bool h) __attribute__((always_inline)) {
+        u64 m = __ballot(h);
+        while (m) {  // wave-uniform
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            int q = __builtin_amdgcn_readlane((int)inf.x, src);
+            const int ee = q + __builtin_amdgcn_readlane((int)inf.y, src);
+            unsigned c = (unsigned)__builtin_amdgcn_readlane((int)inf.z, src);
+            float v = __int_as_float(__builtin_amdgcn_readlane((int)inf.w, src));
+            while (true) {
+#pragma unroll
+                for (int i = 0; i < NACC; ++i)
+                    if (c == (unsigned)(lane + 64 * i)) acc[i] += v;
+                if (++q >= ee) break;
+                const uint2 en = ent[q];  // same address in every lane
+                c = en.x;
+                v = __uint_as_float(en.y);
+            }
+        }
+    };
+    auto store_row = [&](const long long row, const float (&acc)[NACC]) __attribute__((always_inline)) {
+        float *out = E + row * (long long)d;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+            if (lane + 64 * i < d) out[lane + 64 * i] = acc[i];
+    };
+    for (long long row0 = wave0 * GR; row0 < n_rows; row0 += nwaves * GR) {
+        long long beg[GR], len_max = 0;
+        int len[GR];
+#pragma unroll
+        for (int r = 0; r < GR; ++r) {
+            const long long row = row0 + r < n_rows ? row0 + r : n_rows - 1;
+            beg[r] = a_indptr[row];
+            const long long l = row0 + r < n_rows ? a_indptr[row + 1] - beg[r] : 0;
+            len[r] = (int)(l < 64 ? l : 64);
+            len_max = l > len_max ? l : len_max;
+        }
+        if (len_max <= 64) {  // (wave-uniform)
+            int f[GR];
+            uint2 w[GR];
+            uint4 info[GR];
+            bool hit[GR];
+#pragma unroll
+            for (int r = 0; r < GR; ++r) f[r] = lane < len[r] ? a_indices[beg[r] + lane] : -1;
+#pragma unroll
+            for (int r = 0; r < GR; ++r) {
+                w[r] = make_uint2(0u, 0u);
+                if (f[r] >= 0 && (long long)f[r] < n_features) w[r] = ftab[f[r] >> 5];
+            }
+#pragma unroll
+            for (int r = 0; r < GR; ++r) {
+                const unsigned bit = 1u << (f[r] & 31);
+                hit[r] = (w[r].x & bit) != 0u;
+                info[r] = make_uint4(0u, 0u, 0u, 0u);
+                if (hit[r]) info[r] = rowinfo[w[r].y + __popc(w[r].x & (bit - 1u))];
+            }
+#pragma unroll
+            for (int r = 0; r < GR; ++r) {
+                if (row0 + r >= n_rows) continue;  // (wave-uniform)
+                float acc[NACC];
+#pragma unroll
+                for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+                apply(acc, info[r], hit[r]);
+                store_row(row0 + r, acc);
+            }
+            continue;
+        }
+        for (int p0 = 0; p0 < GR && row0 + p0 < n_rows; p0 += RPW) {  // long rows, pair by pair
+            const long long prow0 = row0 + p0;
+            long long pbeg[RPW], pend[RPW];
+            int f[RPW][NB];
+            uint2 w[RPW][NB];
+            uint4 info[RPW][NB];
+            bool hit[RPW][NB];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const long long row = prow0 + r < n_rows ? prow0 + r : n_rows - 1;
+                pbeg[r] = a_indptr[row];
+                pend[r] = prow0 + r < n_rows ? a_indptr[row + 1] : pbeg[r];
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const long long pos = pbeg[r] + 64 * u + lane;
+                    f[r][u] = pos < pend[r] ? a_indices[pos] : -1;
+                }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    w[r][u] = make_uint2(0u, 0u);
+                    if (f[r][u] >= 0 && (long long)f[r][u] < n_features) w[r][u] = ftab[f[r][u] >> 5];
+                }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const unsigned bit = 1u << (f[r][u] & 31);
+                    hit[r][u] = (w[r][u].x & bit) != 0u;
+                    info[r][u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (hit[r][u]) info[r][u] = rowinfo[w[r][u].y + __popc(w[r][u].x & (bit - 1u))];
+                }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                if (prow0 + r >= n_rows) continue;  // (wave-uniform)
+                float acc[NACC];
+#pragma unroll
+                for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) apply(acc, info[r][u], hit[r][u]);
+                // rows longer than the 256 ids in flight (the full CSR of a long read): the rest, chunk by chunk
+                for (long long base = pbeg[r] + 64 * NB; base < pend[r]; base += 64 * NB) {
+                    int f2[NB];
+                    uint2 w2[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const long long pos = base + 64 * u + lane;
+                        f2[u] = pos < pend[r] ? a_indices[pos] : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        w2[u] = make_uint2(0u, 0u);
+                        if (f2[u] >= 0 && (long long)f2[u] < n_features) w2[u] = ftab[f2[u] >> 5];
+                    }
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const unsigned bit = 1u << (f2[u] & 31);
+                        const bool h2 = (w2[u].x & bit) != 0u;
+                        uint4 i2 = make_uint4(0u, 0u, 0u, 0u);
+                        if (h2) i2 = rowinfo[w2[u].y + __popc(w2[u].x & (bit - 1u))];
+                        apply(acc, i2, h2);
+                    }
+                }
+                store_row(prow0 + r, acc);
+            }
+        }
+    }
+}
+
+// d > 512 (16+ accumulators per lane and row): two rows per wave and turn, four chunks each -- round 3's kernel; with the
+// eight-row turns above hipcc no longer unrolls its loops at DP = 2048 (a stack array, 144 B of scratch).
+template <int DP>
+__global__ __launch_bounds__(256) void embed_csr_wide_kernel(
     long long n_rows, const long long *__restrict__ a_indptr, const int *__restrict__ a_indices,
     long long n_features, const uint2 *__restrict__ ftab, const uint4 *__restrict__ rowinfo,
     const uint2 *__restrict__ ent, int d, float *__restrict__ E) {
@@ -568,25 +728,29 @@ static int launch_embed(fdr_ctx *ctx, int64_t n_rows, const int64_t *d_indptr,
     if (n_rows < 0) return fail(FDR_E_ARG, "embed: n_rows < 0");
     if (n_rows == 0) return FDR_OK;
     const int dp = fdr_padded_dim(ctx->d);
-    const long long blocks_needed = (n_rows + 7) / 8;  // (four waves per block, two rows per wave and turn)
+    const long long blocks_needed = (n_rows + 7) / 8;  // (four waves per block, two to eight rows per wave and turn; grid-stride)
     const int grid = (int)std::min<long long>(blocks_needed, (long long)ctx->num_cus * 8 * 4);
     int trc = timing_begin(ctx, FDR_KERNEL_EMBED, st);
     if (trc) return trc;
 #define FDR_LAUNCH_EMBED(DP_)                                                                   \
-    hipLaunchKernelGGL(embed_csr_kernel<DP_>, dim3(grid), dim3(256), 0, st, (long long)n_rows,  \
+    hipLaunchKernelGGL(FDR_EMBED_KERNEL<DP_>, dim3(grid), dim3(256), 0, st, (long long)n_rows,  \
                        (const long long *)d_indptr, d_indices, ctx->n_features,                 \
                        (const uint2 *)ctx->ftab.p, (const uint4 *)ctx->crow.p,                  \
                        (const uint2 *)ctx->ent.p, ctx->d, d_E)
+#define FDR_EMBED_KERNEL embed_csr_kernel
     if (dp == 128)
         FDR_LAUNCH_EMBED(128);
     else if (dp == 256)
         FDR_LAUNCH_EMBED(256);
     else if (dp == 512)
         FDR_LAUNCH_EMBED(512);
+#undef FDR_EMBED_KERNEL
+#define FDR_EMBED_KERNEL embed_csr_wide_kernel
     else if (dp == 1024)
         FDR_LAUNCH_EMBED(1024);
     else
         FDR_LAUNCH_EMBED(2048);
+#undef FDR_EMBED_KERNEL
 #undef FDR_LAUNCH_EMBED
     HIP_TRY(hipGetLastError());
     return timing_end(ctx, FDR_KERNEL_EMBED, st);
