@@ -119,6 +119,31 @@ def test_embed_empty_rows_and_long_rows(ctx, oracle):
     assert not E[0].any() and not E[5].any() and not E[8].any()
 
 
+@pytest.mark.parametrize("d", [128, 500])
+def test_embed_short_rows_eight_per_wave(ctx, oracle, d):
+    """Rows of at most 64 ids -- what a compacted CSR holds -- take the embed kernel's short-row path: eight rows per
+    wave and turn, one chunk each.  Lengths at the chunk's edges (0, 1, 63, 64), a row count that leaves the last
+    group partly filled, a projection whose rows hold several entries; then the same rows with one long row in every
+    third group (those groups take the long-row path)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21 + d)
+    F = 8192
+    P = sp.random(F, d, density=0.02, format="csr", dtype=np.float32, random_state=5,
+                  data_rvs=lambda n: rng.standard_normal(n).astype(np.float32))
+    P.sort_indices()
+    lens = rng.choice([0, 1, 2, 17, 40, 63, 64], size=8 * 150 + 3)
+    rows = [np.sort(rng.choice(F, size=int(n), replace=False)) for n in lens]
+    ctx.projection_load(P.indptr, P.indices, P.data, F, d)
+    for variant in range(2):
+        if variant == 1:
+            for g in range(0, len(rows) - 8, 24):
+                rows[g + 5] = np.sort(rng.choice(F, size=65 + g % 400, replace=False))
+        indptr, indices = oracle.rows_to_csr(rows)
+        E = ctx.embed(indptr, indices.astype(np.int32))
+        want = oracle.embed(indptr, indices, (P.indptr, P.indices, P.data), F, d)
+        assert np.array_equal(_bits(E), _bits(want))
+
+
 def test_embed_dense_projection_rows(ctx, oracle):
     # a projection where most features have several entries: exercises the multi-entry loop
     rng = np.random.default_rng(10)
